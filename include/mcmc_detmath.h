@@ -1,0 +1,142 @@
+/*
+ * mcmc_detmath.h -- deterministic double-precision cos() and exp().
+ *
+ * Why this exists: the reference calls libm's std::cos (covid.h:619, the behaviour
+ * proposal) and std::exp (mcmc.h:776, the acceptance test).  glibc's and the GPU's
+ * (ocml) implementations differ in the last bit for some arguments, which would make
+ * the chain state on the GPU drift from a CPU run by an ulp and defeat bit-exact
+ * comparison.  Both the HIP kernels and the CPU oracle therefore use the two functions
+ * below: a Cody-Waite reduction plus minimax polynomials in the style of the classic
+ * Sun fdlibm algorithms (restated from the published method; error < 1 ulp, checked
+ * against libm in tests/test_detmath.py).  Every operation is a single IEEE-754
+ * double operation in a fixed order, so the result is identical on any conforming
+ * target as long as the translation unit is compiled with floating-point contraction
+ * OFF (-ffp-contract=off): no FMA may be formed here.
+ *
+ * Usable from C99, C++ and HIP device code.
+ */
+#ifndef MCMC_DETMATH_H
+#define MCMC_DETMATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define MCMC_HD __host__ __device__ static inline
+#else
+#define MCMC_HD static inline
+#endif
+
+MCMC_HD double mcmc_bits2d(uint64_t u) {
+    union { uint64_t u; double d; } x; x.u = u; return x.d;
+}
+MCMC_HD uint64_t mcmc_d2bits(double d) {
+    union { uint64_t u; double d; } x; x.d = d; return x.u;
+}
+
+/* round-to-nearest-even of a double with |x| < 2^51 without calling libm */
+MCMC_HD double mcmc_rint_small(double x) {
+    const double big = 6755399441055744.0; /* 1.5 * 2^52 */
+    double t = x + big;
+    return t - big;
+}
+
+/* cos on [-pi/4, pi/4] of x + y (y = tail of the reduced argument) */
+MCMC_HD double mcmc_kcos(double x, double y) {
+    const double C1 =  4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 =  2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 =  2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = x * x;
+    double w = z * z;
+    double r = z * (C1 + z * (C2 + z * C3)) + (w * w) * (C4 + z * (C5 + z * C6));
+    double hz = 0.5 * z;
+    w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + (z * r - x * y));
+}
+
+/* sin on [-pi/4, pi/4] of x + y */
+MCMC_HD double mcmc_ksin(double x, double y) {
+    const double S1 = -1.66666666666666324348e-01, S2 =  8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 =  2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 =  1.58969099521155010221e-10;
+    double z = x * x;
+    double w = z * z;
+    double r = S2 + z * (S3 + z * S4) + (z * w) * (S5 + z * S6);
+    double v = z * x;
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+
+/*
+ * Deterministic cos(x).  Accurate (< 1 ulp) for |x| up to ~1e5, which covers the only
+ * call site (omega*i <= 2*3.1415*5*nB/T < 32, covid.h:604,619).  Larger arguments still
+ * give a deterministic result but lose accuracy (three-term Cody-Waite only).
+ * NaN/Inf give NaN.
+ */
+MCMC_HD double mcmc_cos(double x) {
+    const double invpio2 = 6.36619772367581382433e-01;
+    const double p1  = 1.57079632673412561417e+00;  /* first 33 bits of pi/2 */
+    const double p2  = 6.07710050630396597660e-11;  /* next 33 bits */
+    const double p2t = 2.02226624879595063154e-21;  /* pi/2 - p1 - p2 */
+    double ax = x < 0 ? -x : x;
+    if (!(ax < 1.0e300)) return x - x;   /* inf or nan -> nan (huge finite: garbage-in) */
+    if (ax <= 0.78539816339744827900) return mcmc_kcos(x, 0.0);
+    double fn = mcmc_rint_small(ax * invpio2);
+    /* two-stage Cody-Waite reduction, always both stages: fixed operation count.
+     * pi/2 = p1 + p2 + p2t to ~118 bits; fn*p1 and fn*p2 are exact for fn < 2^20. */
+    double t = ax - fn * p1;
+    double w = fn * p2;
+    double r = t - w;
+    w = fn * p2t - ((t - r) - w);
+    double y0 = r - w;
+    double y1 = (r - y0) - w;
+    int64_t n = (int64_t)fn;
+    switch (n & 3) {
+        case 0:  return  mcmc_kcos(y0, y1);
+        case 1:  return -mcmc_ksin(y0, y1);
+        case 2:  return -mcmc_kcos(y0, y1);
+        default: return  mcmc_ksin(y0, y1);
+    }
+}
+
+/*
+ * Deterministic exp(x).  Overflow -> +inf, underflow -> 0 (through subnormals),
+ * NaN -> NaN.
+ */
+MCMC_HD double mcmc_exp(double x) {
+    const double o_thr =  7.09782712893383973096e+02;
+    const double u_thr = -7.45133219101941108420e+02;
+    const double ln2hi =  6.93147180369123816490e-01;
+    const double ln2lo =  1.90821492927058770002e-10;
+    const double invln2 = 1.44269504088896338700e+00;
+    const double P1 =  1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                 P3 =  6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+                 P5 =  4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > o_thr) return mcmc_bits2d(0x7ff0000000000000ULL);
+    if (x < u_thr) return 0.0;
+    double ax = x < 0 ? -x : x;
+    double hi = 0.0, lo = 0.0;
+    int k = 0;
+    if (ax > 0.34657359027997264) {            /* |x| > 0.5 ln2 */
+        double kf = mcmc_rint_small(x * invln2);
+        k = (int)kf;
+        hi = x - kf * ln2hi;
+        lo = kf * ln2lo;
+        x = hi - lo;
+    } else if (ax < 3.725290298461914e-09) {   /* |x| < 2^-28 */
+        return 1.0 + x;
+    }
+    double t = x * x;
+    double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    double y;
+    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+    y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+    /* scale by 2^k in two exact steps so subnormal results round once */
+    if (k >= -1021) {
+        if (k == 1024) return (y * 2.0) * mcmc_bits2d(0x7fe0000000000000ULL);
+        return y * mcmc_bits2d((uint64_t)(0x3ff + k) << 52);
+    }
+    return (y * mcmc_bits2d((uint64_t)(0x3ff + (k + 1000)) << 52)) *
+           mcmc_bits2d((uint64_t)(0x3ff - 1000) << 52);
+}
+
+#endif /* MCMC_DETMATH_H */

@@ -1,0 +1,186 @@
+/*
+ * mcmc_hip.h -- C ABI of the MI355X Metropolis-Hastings hot path (libmcmc_hip.so).
+ *
+ * This is the drop-in boundary: the entry points a binding of AndreasFinke/mcmc would
+ * call in place of running `MetropolisChain::run` (mcmc.h:1005-1138) on every chain
+ * inside `ChainManager::run_all*`'s tbb::parallel_for (mcmc.h:1494-1508, 1534-1548).
+ * Plain pointers and sizes only; the library owns all device memory behind the opaque
+ * context; the caller owns every host buffer.  Every function returns 0 on success or
+ * a negative MCMC_HIP_E* code; mcmc_hip_last_error() gives the message (thread-local).
+ * No exception crosses the boundary.  A context is single-owner and not thread-safe
+ * (the reference's chains share nothing mutable either, mcmc.h:1479,1520).
+ *
+ * All reference citations are file:line under /root/reference.
+ */
+#ifndef MCMC_HIP_H
+#define MCMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCMC_HIP_OK            0
+#define MCMC_HIP_EINVAL       -1   /* bad argument / inconsistent sizes              */
+#define MCMC_HIP_ESTATE       -2   /* call order violated (e.g. run before set_*)    */
+#define MCMC_HIP_EHIP         -3   /* a HIP runtime call failed                      */
+#define MCMC_HIP_ENOMEM       -4
+#define MCMC_HIP_ENODEVICE    -5   /* no usable gfx950 device                        */
+
+/* number of response curves the model reads, in this order (covid.h:403-410,426-428):
+ * infectiousMild, infectiousHigh, incubating, mild, serious, recovered, dead,
+ * seriousFromSerious, recoveredFromSerious, deadFromSerious.  (`asymptomatic` is
+ * projected with traj.mild, covid.h:406, so it needs no curve of its own.) */
+#define MCMC_HIP_NCURVES 10
+#define MCMC_HIP_TRAJ_NDAYS 500           /* AvgDiseaseTrajectory::nDays, covid.h:206 */
+
+enum mcmc_target_kind {                    /* mcmc.h:705-841 */
+    MCMC_TARGET_PLAIN = 0,                 /* Target:        beta = 1                   */
+    MCMC_TARGET_TEMP = 1,                  /* TempTarget:    beta = 1/T                 */
+    MCMC_TARGET_COOLING = 2                /* CoolingTarget: beta = exp(t*slope)/Tinit  */
+};
+
+/* DiseaseParams (covid.h:59-93): the 15 public fields, same names. */
+typedef struct mcmc_disease_params {
+    double timeIncub, timeIncubSigma, probAsymp, probSerious, probLethal,
+           probLethalDailyWhenSeriousUntreated, probICUIfSerious,
+           timeMildDuration, timeMildDurationSigma, timeMildToSerious,
+           timeMildToSeriousSigma, timeSeriousToRec, timeSeriousToRecSigma,
+           timeSeriousToDeath, timeSeriousToDeathSigma;
+} mcmc_disease_params;
+
+/* Everything DiseaseSpread's ctor (covid.h:294-321), DiseaseData (covid.h:16-57),
+ * SmoothnessPrior's ctor (mcmc.h:188) and the Target (mcmc.h:797-841) fix per run. */
+typedef struct mcmc_covid_config {
+    int32_t n_data;                  /* data.deathsPerDay.size()                       */
+    int32_t max_delay;               /* maxDelayDaysTilData                            */
+    int32_t n_predict;               /* nPredictDays                                   */
+    int32_t n_disc;                  /* data.discontinuousDays.size(), 1..8            */
+    int32_t fix_behavior_in_advance; /* data.fixBehaviorInAdvance                      */
+    int32_t pop_size;                /* int popSize (covid.h:292)                      */
+    double  prob_icu_if_serious;     /* params.probICUIfSerious                        */
+    double  prob_lethal_daily_untreated; /* params.probLethalDailyWhenSeriousUntreated */
+    double  cap0, cap_incr_rate;     /* capacity[i] = cap0 + max(rate*(i-maxDelay),0)  */
+    int32_t has_prior;               /* 1: State = [DiseaseSpread, SmoothnessPrior("behavior")] */
+    double  smooth_Ls, smooth_L;     /* SmoothnessPrior(name, smoothnessScale, scale)  */
+    int32_t target_kind;             /* enum mcmc_target_kind                          */
+    double  target_T, target_slope, target_Tinit;
+    int32_t contract;                /* 0: every projection term is mul then add (the C++
+                                        source semantics); 1: projection terms are fused
+                                        multiply-adds, as gcc -ffp-contract=fast compiles
+                                        `dest[d+k] += n*cumsum` (covid.h:384)          */
+    const int32_t* disc_days;        /* [n_disc] data.discontinuousDays                */
+    const uint8_t* disc_fixed;       /* [n_disc] data.discontinuousValsFixed           */
+} mcmc_covid_config;
+
+typedef struct mcmc_hip_ctx mcmc_hip_ctx;
+
+const char* mcmc_hip_last_error(void);
+/* gfx950 devices visible to this process (HIP_VISIBLE_DEVICES applies). */
+int mcmc_hip_device_count(void);
+
+/* --- host-side precompute (AvgDiseaseTrajectory, covid.h:96-282; runs on the CPU as in
+ * the reference, once per model) ------------------------------------------------------
+ * Fills R[MCMC_HIP_NCURVES][n_lag], R[c][d] = the running sum `cumsum` that project()
+ * (covid.h:377-384) forms from getDay(0..d) of curve c.  n_traj = 10000000 reproduces
+ * AvgDiseaseTrajectory::nTrajectories.  n_lag <= MCMC_HIP_TRAJ_NDAYS. */
+int mcmc_host_make_response_tables(const mcmc_disease_params* p, uint64_t n_traj,
+                                   int32_t n_lag, double* R);
+void mcmc_host_default_disease_params(mcmc_disease_params* p);          /* covid.h:75-90 */
+/* Synthetic initial conditions: chain c, coordinate k (chain-major draw order from one
+ * pcg32(initstate, initseq)): out[c*dim+k] = x0[k] + (nextFloat()-.5f)*x0[k]*a, the
+ * per-coordinate rule of State::perturb (mcmc.h:306-314). */
+int mcmc_host_perturb_ics(const double* x0, int32_t dim, int64_t n_chains, double a,
+                          uint64_t initstate, uint64_t initseq, double* out);
+
+/* --- context ------------------------------------------------------------------------
+ * Replaces constructing DiseaseSpread/SmoothnessPrior/State/Target (covid.h:294,
+ * mcmc.h:188,268,709).  `device` is the HIP ordinal this context (and its process) uses. */
+int mcmc_hip_create(const mcmc_covid_config* cfg, int device, mcmc_hip_ctx** out);
+int mcmc_hip_destroy(mcmc_hip_ctx* ctx);
+
+/* AvgDiseaseTrajectory as the model reads it: R[MCMC_HIP_NCURVES][n_lag] with
+ * n_lag >= min(500, size); replaces `AvgDiseaseTrajectory traj` (covid.h:290). */
+int mcmc_hip_set_tables(mcmc_hip_ctx* ctx, const double* R, int32_t n_lag);
+/* data.deathsPerDay / data.deathsSigma (covid.h:47), each [n_data]. */
+int mcmc_hip_set_data(mcmc_hip_ctx* ctx, const double* deaths, const double* sigma);
+
+/* Replaces ChainManager's per-chain setup loop (mcmc.h:1517-1532): n chains, chain i has
+ * RNG pcg32(0, chain_ids[i]) (mcmc.h:999,1527) and parameters params[i*dim .. i*dim+dim)
+ * in the reference's coords order: behavior[nB], discontinuousVals[nDisc], betaMild,
+ * betaHigh, delay (covid.h:294,299-301); dim = nB+nDisc+3.  stepsizes[i] =
+ * stepsizeCorrectionFac of the DiseaseSpread sub-state (NULL: all 1).  chain_ids NULL:
+ * first_chain_id+i.  Evaluates the initial log-likelihoods on the device (State::eval,
+ * mcmc.h:385-393).  Chains are independent: a caller sharding over GPUs gives each
+ * context its own id range (mcmc.h:1487). */
+int mcmc_hip_set_chains(mcmc_hip_ctx* ctx, int64_t n_chains, const double* params,
+                        const double* stepsizes, const uint64_t* chain_ids,
+                        uint64_t first_chain_id);
+
+/* Replaces `chains[i].run(nSamples, nBurnin, nAdjust, thinning)` for ALL chains
+ * (mcmc.h:1005-1138 under mcmc.h:1494-1508 / 1534-1548).  record_samples mirrors
+ * MetropolisChain::recordSamples, compute_mean mirrors computeMean.  May be called again:
+ * like a second chain.run() it continues from the current state and RNG, and replaces
+ * the recorded loglikes/samples. */
+int mcmc_hip_run(mcmc_hip_ctx* ctx, int32_t n_samples, int32_t n_burnin, int32_t n_adjust,
+                 int32_t thinning, int32_t record_samples, int32_t compute_mean);
+/* Finer-grained driver used by tests and by callers that interleave their own work:
+ * advance every chain by n_steps Target::step calls (mcmc.h:750-783) at inverse
+ * temperature beta; random_subspace as the 4th argument of Target::step. */
+int mcmc_hip_step(mcmc_hip_ctx* ctx, int32_t n_steps, double beta, int32_t random_subspace);
+
+/* number of entries MetropolisChain::loglikes would hold (mcmc.h:1037) */
+int32_t mcmc_hip_n_saved(int32_t n_samples, int32_t n_burnin, int32_t n_adjust, int32_t thinning);
+
+/* --- results (all copy out; layouts are chain-major = what per-chain getters return) -- */
+int mcmc_hip_dim(const mcmc_hip_ctx* ctx);           /* nB + nDisc + 3                     */
+int mcmc_hip_size(const mcmc_hip_ctx* ctx);          /* nDaysTotal (covid.h:297)           */
+int64_t mcmc_hip_n_chains(const mcmc_hip_ctx* ctx);
+int mcmc_hip_get_params(mcmc_hip_ctx* ctx, double* out /*[n_chains][dim]*/);
+int mcmc_hip_get_loglike(mcmc_hip_ctx* ctx, double* out /*[n_chains][2]: model, prior*/);
+int mcmc_hip_get_stepsizes(mcmc_hip_ctx* ctx, double* out /*[n_chains]*/);
+int mcmc_hip_get_accept_counts(mcmc_hip_ctx* ctx, int32_t* out /*[n_chains] run()'s nAccept*/);
+int mcmc_hip_get_rng_state(mcmc_hip_ctx* ctx, uint64_t* out /*[n_chains][2]: state, inc*/);
+/* MetropolisChain::get_loglikes (mcmc.h:1286-1301) for every chain */
+int mcmc_hip_get_loglikes(mcmc_hip_ctx* ctx, double* out /*[n_chains][n_saved]*/);
+/* MetropolisChain::get_samples (mcmc.h:1249-1268) restricted to sampled coordinates
+ * [coord_first, coord_first+coord_count) of one chain: out[n_saved][coord_count]. */
+int mcmc_hip_get_samples(mcmc_hip_ctx* ctx, int64_t chain, int32_t coord_first,
+                         int32_t coord_count, double* out);
+/* every chain, one saved sample: out[n_chains][dim] */
+int mcmc_hip_get_sample_all(mcmc_hip_ctx* ctx, int32_t saved_index, double* out);
+/* MetropolisChain::get_mean (mcmc.h:1236-1248): out[n_chains][dim] */
+int mcmc_hip_get_mean(mcmc_hip_ctx* ctx, double* out);
+
+/* Parity hook / batched likelihood (DiseaseSpread::eval + SmoothnessPrior::eval,
+ * covid.h:325-496, mcmc.h:197-214) of n parameter vectors, without touching chain state:
+ * ll_out[n][2].  Also what ChainManager's reservoir constructors need (mcmc.h:1356-1371). */
+int mcmc_hip_eval(mcmc_hip_ctx* ctx, int64_t n, const double* params /*[n][dim]*/, double* ll_out);
+/* The derived output coords of DiseaseSpread::eval (covid.h:467-485) for n parameter
+ * vectors: curves_out[n][9][size] in the order mildlyInfectious, highlyInfectious,
+ * incubating, asymptomatic, mild, serious, recovered, dead, totalBehavior -- computed
+ * only on request (the reference's compute_derived_late idea, mcmc.h:100-104). */
+int mcmc_hip_derive(mcmc_hip_ctx* ctx, int64_t n, const double* params, double* curves_out);
+
+/* Cross-chain diagnostics of the current state, reduced on the device with wavefront
+ * shuffle reductions: out[0]=sum of run()'s nAccept, out[1]=number of Target::step calls
+ * per chain since set_chains/run start, out[2]=sum loglike, out[3]=sum loglike^2,
+ * then per coordinate k<dim: out[4+2k]=sum x_k, out[5+2k]=sum x_k^2.  Length 4+2*dim.
+ * A multi-GPU caller all-reduces this vector (it is additive over shards). */
+int mcmc_hip_diagnostics(mcmc_hip_ctx* ctx, double* out);
+
+/* wall time (s) the last mcmc_hip_run spent in its sampling phase and adjust phase,
+ * measured with hipEvents on the library's stream, plus the kernel-only time of the
+ * step kernel and the number of its launches (for roofline accounting). */
+int mcmc_hip_last_timing(mcmc_hip_ctx* ctx, double* adjust_s, double* sampling_s,
+                         double* step_kernel_s, int64_t* step_kernel_launches);
+/* algorithmic (day,lag) pairs the step kernel executed since the counter was reset,
+ * summed over chains: each pair is one multiply-add per compartment (covid.h:384). */
+int mcmc_hip_pair_count(mcmc_hip_ctx* ctx, double* pairs_out, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCMC_HIP_H */

@@ -1,0 +1,776 @@
+/*
+ * mcmc_hip.hip -- C-ABI implementation (include/mcmc_hip.h) over the kernels of
+ * mcmc_kernels.hip.h.  Host side: context/ownership, the one-off response-table
+ * precompute (AvgDiseaseTrajectory, covid.h:96-282), the step schedule of
+ * MetropolisChain::run (mcmc.h:1005-1138) and result copies.  Plain HIP runtime only.
+ *
+ * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+ */
+#include "mcmc_hip.h"
+#include "mcmc_kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#ifndef MCMC_T
+#define MCMC_T 8           /* days per register block, see mcmc_kernels.hip.h */
+#endif
+#ifndef MCMC_T_DERIVE
+#define MCMC_T_DERIVE 4    /* the derive kernel is not a hot path: small block, short compile */
+#endif
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(MCMC_HIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+template <typename Tp>
+struct DevBuf {
+    Tp* p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        release();
+        if (count == 0) return 0;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(Tp));
+        if (e != hipSuccess) { p = nullptr; return fail(MCMC_HIP_ENOMEM, "hipMalloc(%zu B): %s", count * sizeof(Tp), hipGetErrorString(e)); }
+        n = count;
+        return 0;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    ~DevBuf() { release(); }
+};
+
+}  // namespace
+
+struct mcmc_hip_ctx {
+    mcmc_covid_config cfg{};
+    std::vector<int32_t> discDays;
+    std::vector<uint8_t> discFixed;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int size = 0, nB = 0, dim = 0, simDays = 0, simPad = 0, nLag = 0, tabRows = 0, histRows = 0;
+    bool haveTables = false, haveData = false, haveChains = false;
+    DevModel M{};
+    ChainState S{};
+    long long nChains = 0, nP = 0;
+    int nSaved = 0, nSavedCap = 0;
+    bool recSamples = false;
+    /* model constants */
+    DevBuf<double> dRpos, dRneg, dCapacity, dDeaths, dSigma2;
+    DevBuf<int> dSeg;
+    /* chain state */
+    DevBuf<double> dParams, dLL, dStepsize, dHn, dHe, dD1s, dMean, dRecLL, dRecSamples;
+    DevBuf<uint64_t> dRng;
+    DevBuf<int> dNAccept;
+    DevBuf<unsigned long long> dPairs;
+    /* scratch */
+    DevBuf<double> dBetas;
+    DevBuf<int> dFlags;
+    /* timing */
+    double adjustS = 0, samplingS = 0, kernelS = 0;
+    long long kernelLaunches = 0;
+    unsigned long long stepsDone = 0;
+};
+
+namespace {
+
+/* ------------------------------------------------------------ host precompute ---- */
+struct HostPcg {
+    uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;   /* pcg32() */
+    uint32_t next_uint() {
+        uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        uint32_t x = (uint32_t)(((old >> 18u) ^ old) >> 27u), r = (uint32_t)(old >> 59u);
+        return (x >> r) | (x << ((~r + 1u) & 31));
+    }
+    float next_float() { uint32_t u = (next_uint() >> 9) | 0x3f800000u; float f; memcpy(&f, &u, 4); return f - 1.0f; }
+    double next_double() { uint64_t u = ((uint64_t)next_uint() << 20) | 0x3ff0000000000000ULL; double d; memcpy(&d, &u, 8); return d - 1.0; }
+};
+
+/* enoki::erfinv as used by toNormal (mcmc.h:45-47): Giles' single-precision polynomial */
+double erfinv_giles(double x) {
+    double w = -std::log((1.0 - x) * (1.0 + x));
+    static const double lo[9] = {2.81022636e-08, 3.43273939e-07, -3.5233877e-06, -4.39150654e-06,
+                                 0.00021858087, -0.00125372503, -0.00417768164, 0.246640727, 1.50140941};
+    static const double hi[9] = {-0.000200214257, 0.000100950558, 0.00134934322, -0.00367342844,
+                                 0.00573950773, -0.0076224613, 0.00943887047, 1.00167406, 2.83297682};
+    const double* c;
+    if (w < 5.0) { w = w - 2.5; c = lo; } else { w = std::sqrt(w) - 3.0; c = hi; }
+    double p = c[0];
+    for (int i = 1; i < 9; ++i) p = c[i] + p * w;
+    return p * x;
+}
+
+constexpr size_t kGrid = 100000;      /* AvgDiseaseTrajectory::nGrid, covid.h:205 */
+constexpr size_t kDays = MCMC_HIP_TRAJ_NDAYS;
+
+/* AvgDiseaseTrajectory ctor (covid.h:100-203) -> the 11 cumulative curves on the grid */
+struct Trajectories {
+    enum { INCUB, ASYMP, MILD, INFMILD, INFHIGH, SERIOUS, DEAD, RECOV, SFS, RFS, DFS, N };
+    std::vector<double> a[N];
+    static size_t slot(double t) {                                   /* t2i, covid.h:273-280 */
+        double v = (double)kGrid * (t / (double)kDays);
+        return (v < (double)kGrid) ? (size_t)v : kGrid - 1;
+    }
+    /* sampleTime (covid.h:262-271) receives the generator by value: a peek */
+    static double sample_time(HostPcg rnd, double mean, double sig) {
+        double s = std::sqrt(std::log(sig * sig / (mean * mean) + 1));
+        double expmu = mean * std::exp(-0.5 * s * s);
+        double u;
+        do { u = rnd.next_double(); } while (u <= 0 || u >= 1);
+        double n = M_SQRT2 * erfinv_giles(2.0 * u - 1.0) * s;
+        return expmu * std::exp(n);
+    }
+    void generate(const mcmc_disease_params& p, uint64_t nTraj) {
+        for (auto& v : a) v.assign(kGrid, 0.0);
+        HostPcg rnd;
+        for (uint64_t k = 0; k < nTraj; ++k) {
+            a[INCUB][0] += 1;
+            const double t = sample_time(rnd, p.timeIncub, p.timeIncubSigma);
+            const size_t it = slot(t);
+            a[INCUB][it] -= 1;
+            if (rnd.next_double() < p.probAsymp) {
+                a[ASYMP][it] += 1; a[INFHIGH][it] += 1;
+                const size_t i2 = slot(t + sample_time(rnd, p.timeMildDuration, p.timeMildDurationSigma));
+                a[ASYMP][i2] -= 1; a[RECOV][i2] += 1; a[INFHIGH][i2] -= 1;
+            } else {
+                a[MILD][it] += 1; a[INFMILD][it] += 1;
+                if ((int)it - 1 > 0) { a[INFHIGH][it - 1] += 1; a[INFHIGH][it] -= 1; }
+                const double x = rnd.next_double();
+                if (x < 1 - (p.probSerious + p.probLethal) / (1 - p.probAsymp)) {
+                    const size_t i2 = slot(t + sample_time(rnd, p.timeMildDuration, p.timeMildDurationSigma));
+                    a[MILD][i2] -= 1; a[INFMILD][i2] -= 1; a[RECOV][i2] += 1;
+                } else {
+                    const double t2 = sample_time(rnd, p.timeMildToSerious, p.timeMildToSerious); /* covid.h:142 */
+                    const size_t i2 = slot(t + t2);
+                    a[INFMILD][i2] -= 1; a[SERIOUS][i2] += 1; a[MILD][i2] -= 1;
+                    double t3;
+                    if (x < 1 - p.probLethal / (1 - p.probAsymp)) {
+                        t3 = sample_time(rnd, p.timeSeriousToRec, p.timeSeriousToRecSigma);
+                        a[RECOV][slot(t + t2 + t3)] += 1;
+                    } else {
+                        t3 = sample_time(rnd, p.timeSeriousToDeath, p.timeSeriousToDeathSigma);
+                        a[DEAD][slot(t + t2 + t3)] += 1;
+                    }
+                    a[SERIOUS][slot(t + t2 + t3)] -= 1;
+                }
+            }
+            const double x = rnd.next_double();
+            a[SFS][0] += 1;
+            double t3;
+            if (x < p.probSerious / (p.probLethal + p.probSerious)) {
+                t3 = sample_time(rnd, p.timeSeriousToRec, p.timeSeriousToRecSigma);
+                a[RFS][slot(t3)] += 1;
+            } else {
+                t3 = sample_time(rnd, p.timeSeriousToDeath, p.timeSeriousToDeathSigma);
+                a[DFS][slot(t3)] += 1;
+            }
+            a[SFS][slot(t3)] -= 1;
+        }
+        const double nt = (double)nTraj;
+        for (auto& v : a) {
+            v[0] /= nt;
+            for (size_t t = 1; t < kGrid; ++t) v[t] = v[t - 1] + v[t] / nt;
+        }
+    }
+    /* getDay, covid.h:221-235 */
+    static double day_delta(const std::vector<double>& ar, size_t day) {
+        if (day == 0) return ar[0];
+        if (day == kDays) return 0;
+        const size_t i1 = (size_t)((double)kGrid * ((double)(day - 1) / (double)kDays));
+        const size_t i2 = (size_t)((double)kGrid * ((double)day / (double)kDays));
+        if (i2 > kGrid - 1) return 0;
+        return ar[i2] - ar[i1];
+    }
+};
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+double target_beta(const mcmc_covid_config& c, double time) {
+    switch (c.target_kind) {
+        case MCMC_TARGET_TEMP: return 1 / c.target_T;                         /* mcmc.h:801,806 */
+        case MCMC_TARGET_COOLING: return std::exp(time * c.target_slope) / c.target_Tinit; /* mcmc.h:830 */
+        default: return 1;                                                    /* mcmc.h:742 */
+    }
+}
+
+template <typename K, typename... Args>
+int launch_chain_kernel(mcmc_hip_ctx* c, K kernel, Args... args) {
+    const unsigned grid = (unsigned)(c->nP / MCMC_WAVE);
+    const size_t shmem = lds_bytes(c->simPad, c->cfg.n_data);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(MCMC_WAVE), shmem, c->stream, args...);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int run_eval_current(mcmc_hip_ctx* c) {
+    if (c->cfg.contract) return launch_chain_kernel(c, eval_kernel<MCMC_T, true>, c->M, c->S, (const double*)c->S.params, c->S.ll, c->simPad);
+    return launch_chain_kernel(c, eval_kernel<MCMC_T, false>, c->M, c->S, (const double*)c->S.params, c->S.ll, c->simPad);
+}
+
+int launch_steps(mcmc_hip_ctx* c, int nSteps, const double* dBetas, const int* dFlags, int slot0) {
+    if (c->cfg.contract)
+        return launch_chain_kernel(c, mh_step_kernel<MCMC_T, true>, c->M, c->S, nSteps, dBetas, dFlags, slot0, c->simPad);
+    return launch_chain_kernel(c, mh_step_kernel<MCMC_T, false>, c->M, c->S, nSteps, dBetas, dFlags, slot0, c->simPad);
+}
+
+int check_ctx(const mcmc_hip_ctx* c) {
+    if (!c) return fail(MCMC_HIP_EINVAL, "null context");
+    return 0;
+}
+
+/* Runs a prepared schedule in launches of at most `perLaunch` steps, timing the kernels. */
+int run_schedule(mcmc_hip_ctx* c, const std::vector<double>& betas, const std::vector<int>& flags,
+                 size_t first, size_t last, int perLaunch, double* wallS) {
+    if (last <= first) { if (wallS) *wallS = 0; return 0; }
+    const size_t n = last - first;
+    if (c->dBetas.n < n) { if (int r = c->dBetas.alloc(n)) return r; }
+    if (c->dFlags.n < n) { if (int r = c->dFlags.alloc(n)) return r; }
+    HIP_TRY(hipMemcpyAsync(c->dBetas.p, betas.data() + first, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->dFlags.p, flags.data() + first, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    int slot = 0;
+    for (size_t g = 0; g < first; ++g) if (flags[g] & SF_RECORD) ++slot;
+    double total = 0;
+    for (size_t off = 0; off < n; off += (size_t)perLaunch) {
+        const int cnt = (int)std::min((size_t)perLaunch, n - off);
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        if (int r = launch_steps(c, cnt, c->dBetas.p + off, c->dFlags.p + off, slot)) return r;
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        HIP_TRY(hipEventSynchronize(c->ev1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        total += ms * 1e-3;
+        c->kernelS += ms * 1e-3;
+        c->kernelLaunches += 1;
+        for (int g = 0; g < cnt; ++g) if (flags[first + off + g] & SF_RECORD) ++slot;
+        c->stepsDone += (unsigned long long)cnt;
+    }
+    if (wallS) *wallS = total;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mcmc_hip_last_error(void) { return g_err.c_str(); }
+
+int mcmc_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void mcmc_host_default_disease_params(mcmc_disease_params* p) {
+    if (!p) return;
+    *p = mcmc_disease_params{4, 2, 0.1, 0.08, 0.004, 0.2, 0.3, 10, 5, 8, 3, 10, 5, 9, 5};
+}
+
+int mcmc_host_make_response_tables(const mcmc_disease_params* p, uint64_t n_traj, int32_t n_lag, double* R) {
+    if (!p || !R || n_lag < 1 || n_lag > MCMC_HIP_TRAJ_NDAYS || n_traj == 0)
+        return fail(MCMC_HIP_EINVAL, "make_response_tables: bad arguments");
+    Trajectories tr;
+    tr.generate(*p, n_traj);
+    /* curve order of MCMC_HIP_NCURVES */
+    const int order[MCMC_HIP_NCURVES] = {Trajectories::INFMILD, Trajectories::INFHIGH, Trajectories::INCUB,
+                                         Trajectories::MILD, Trajectories::SERIOUS, Trajectories::RECOV,
+                                         Trajectories::DEAD, Trajectories::SFS, Trajectories::RFS, Trajectories::DFS};
+    for (int c = 0; c < MCMC_HIP_NCURVES; ++c) {
+        double cumsum = 0;                                           /* covid.h:377-382 */
+        for (int d = 0; d < n_lag; ++d) {
+            cumsum += Trajectories::day_delta(tr.a[order[c]], (size_t)d);
+            R[(size_t)c * n_lag + d] = cumsum;
+        }
+    }
+    return 0;
+}
+
+int mcmc_host_perturb_ics(const double* x0, int32_t dim, int64_t n_chains, double a, uint64_t initstate,
+                          uint64_t initseq, double* out) {
+    if (!x0 || !out || dim < 1 || n_chains < 0) return fail(MCMC_HIP_EINVAL, "perturb_ics: bad arguments");
+    HostPcg r;
+    pcg32_seed(r.state, r.inc, initstate, initseq);
+    for (int64_t c = 0; c < n_chains; ++c)
+        for (int k = 0; k < dim; ++k)
+            out[c * dim + k] = x0[k] + (r.next_float() - .5f) * x0[k] * a;   /* mcmc.h:310 */
+    return 0;
+}
+
+int32_t mcmc_hip_n_saved(int32_t n_samples, int32_t n_burnin, int32_t n_adjust, int32_t thinning) {
+    if (thinning < 1) return 0;
+    int32_t n = 0;
+    for (int32_t i = 0; i < n_samples + n_adjust; ++i)
+        if (i >= n_burnin && (i % thinning) == 0) ++n;               /* mcmc.h:1037 */
+    return n;
+}
+
+int mcmc_hip_create(const mcmc_covid_config* cfg, int device, mcmc_hip_ctx** out) {
+    if (!cfg || !out) return fail(MCMC_HIP_EINVAL, "create: null argument");
+    *out = nullptr;
+    if (cfg->n_data < 2 || cfg->max_delay < 1 || cfg->n_predict < 0)
+        return fail(MCMC_HIP_EINVAL, "create: need n_data >= 2, max_delay >= 1, n_predict >= 0");
+    if (cfg->n_disc < 1 || cfg->n_disc > MCMC_MAXDISC || !cfg->disc_days || !cfg->disc_fixed)
+        return fail(MCMC_HIP_EINVAL, "create: n_disc must be 1..%d with disc_days/disc_fixed given", MCMC_MAXDISC);
+    if (cfg->n_data - cfg->fix_behavior_in_advance < 3)
+        return fail(MCMC_HIP_EINVAL, "create: behavior needs at least 3 points (n_data - fix_behavior_in_advance)");
+    if (cfg->pop_size < 1) return fail(MCMC_HIP_EINVAL, "create: pop_size must be positive");
+    if (cfg->target_kind < MCMC_TARGET_PLAIN || cfg->target_kind > MCMC_TARGET_COOLING)
+        return fail(MCMC_HIP_EINVAL, "create: unknown target_kind %d", cfg->target_kind);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(MCMC_HIP_ENODEVICE, "no HIP device visible: the hot path has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(MCMC_HIP_EINVAL, "create: device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    mcmc_hip_ctx* c = new (std::nothrow) mcmc_hip_ctx();
+    if (!c) return fail(MCMC_HIP_ENOMEM, "out of host memory");
+    c->cfg = *cfg;
+    c->discDays.assign(cfg->disc_days, cfg->disc_days + cfg->n_disc);
+    c->discFixed.assign(cfg->disc_fixed, cfg->disc_fixed + cfg->n_disc);
+    c->cfg.disc_days = c->discDays.data();
+    c->cfg.disc_fixed = c->discFixed.data();
+    c->device = device;
+    c->size = cfg->max_delay + cfg->n_predict + cfg->n_data;          /* covid.h:297 */
+    c->nB = cfg->n_data - cfg->fix_behavior_in_advance;               /* covid.h:299 */
+    c->dim = c->nB + cfg->n_disc + 3;
+    c->simDays = cfg->max_delay + cfg->n_data;                        /* what loglike can see */
+    c->simPad = c->size + 2 * MCMC_T;
+    c->nLag = std::min(c->size, (int)MCMC_HIP_TRAJ_NDAYS);            /* covid.h:378 */
+    c->tabRows = c->size + 3 * MCMC_T;
+    c->histRows = c->size + 4 * MCMC_T + MCMC_HOFF(MCMC_T);
+
+    auto cleanup = [&](int r) { mcmc_hip_destroy(c); return r; };
+    if (hipStreamCreate(&c->stream) != hipSuccess) return cleanup(fail(MCMC_HIP_EHIP, "hipStreamCreate failed"));
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
+        return cleanup(fail(MCMC_HIP_EHIP, "hipEventCreate failed"));
+
+    /* per-day constants: capacity (covid.h:314) and the piecewise-constant segment of each
+     * day (covid.h:432-442) */
+    std::vector<double> cap(c->simPad);
+    std::vector<int> seg(c->simPad);
+    const int md = cfg->max_delay, nD = cfg->n_disc;
+    for (int i = 0; i < c->simPad; ++i) {
+        cap[i] = cfg->cap0 + std::max(cfg->cap_incr_rate * (i - md), 0.0);
+        int found = -1;
+        for (int m = 0; m + 1 < nD; ++m)
+            if (c->discDays[m] <= i - md && i - md < c->discDays[m + 1]) { found = m; break; }
+        if (found == -1 && i - md >= c->discDays[nD - 1]) found = nD - 1;
+        seg[i] = found;
+    }
+    if (int r = c->dCapacity.alloc(c->simPad)) return cleanup(r);
+    if (int r = c->dSeg.alloc(c->simPad)) return cleanup(r);
+    if (hipMemcpy(c->dCapacity.p, cap.data(), cap.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->dSeg.p, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        return cleanup(fail(MCMC_HIP_EHIP, "upload of per-day constants failed"));
+
+    float nNotFixed = 0;                                              /* counts the FIXED ones, covid.h:560-563 */
+    unsigned mask = 0;
+    for (int i = 0; i < nD; ++i) if (c->discFixed[i]) { nNotFixed += 1; mask |= 1u << i; }
+
+    DevModel& M = c->M;
+    M.nData = cfg->n_data; M.md = md; M.size = c->size; M.nB = c->nB; M.nDisc = nD;
+    M.simDays = c->simDays; M.nLagRows = c->nLag; M.hasPrior = cfg->has_prior ? 1 : 0;
+    M.pop = (double)cfg->pop_size; M.probICU = cfg->prob_icu_if_serious;
+    M.probLethal = cfg->prob_lethal_daily_untreated;
+    M.smoothLs = cfg->smooth_Ls; M.smoothL = cfg->smooth_L; M.dNData = (double)cfg->n_data;
+    M.discThr = 2 / nNotFixed;                                        /* covid.h:581 (+inf if none fixed) */
+    M.discFixedMask = mask;
+    M.capacity = c->dCapacity.p; M.seg = c->dSeg.p;
+    *out = c;
+    return 0;
+}
+
+int mcmc_hip_destroy(mcmc_hip_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int mcmc_hip_set_tables(mcmc_hip_ctx* c, const double* R, int32_t n_lag) {
+    if (int r = check_ctx(c)) return r;
+    if (!R) return fail(MCMC_HIP_EINVAL, "set_tables: null table");
+    if (n_lag < c->nLag) return fail(MCMC_HIP_EINVAL, "set_tables: n_lag=%d but the model needs %d lags", n_lag, c->nLag);
+    HIP_TRY(hipSetDevice(c->device));
+    /* interleave by lag so that one aligned 64-byte scalar load brings all curves of a lag;
+     * rows >= nLag stay zero: they stand for the d < nDays cut-off of project() (covid.h:378) */
+    std::vector<double> pos((size_t)c->tabRows * 8, 0.0), neg((size_t)c->tabRows * 4, 0.0);
+    for (int d = 0; d < c->nLag; ++d) {
+        for (int k = 0; k < 7; ++k) pos[(size_t)d * 8 + k] = R[(size_t)k * n_lag + d];
+        for (int k = 0; k < 3; ++k) neg[(size_t)d * 4 + k] = R[(size_t)(7 + k) * n_lag + d];
+    }
+    if (int r = c->dRpos.alloc(pos.size())) return r;
+    if (int r = c->dRneg.alloc(neg.size())) return r;
+    HIP_TRY(hipMemcpy(c->dRpos.p, pos.data(), pos.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->dRneg.p, neg.data(), neg.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->M.Rpos = c->dRpos.p;
+    c->M.Rneg = c->dRneg.p;
+    c->haveTables = true;
+    return 0;
+}
+
+int mcmc_hip_set_data(mcmc_hip_ctx* c, const double* deaths, const double* sigma) {
+    if (int r = check_ctx(c)) return r;
+    if (!deaths || !sigma) return fail(MCMC_HIP_EINVAL, "set_data: null series");
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = c->cfg.n_data;
+    std::vector<double> s2(n);
+    for (int i = 0; i < n; ++i) s2[i] = sigma[i] * sigma[i];          /* covid.h:491 */
+    if (int r = c->dDeaths.alloc(n)) return r;
+    if (int r = c->dSigma2.alloc(n)) return r;
+    HIP_TRY(hipMemcpy(c->dDeaths.p, deaths, n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->dSigma2.p, s2.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    c->M.deaths = c->dDeaths.p;
+    c->M.sigma2 = c->dSigma2.p;
+    c->haveData = true;
+    return 0;
+}
+
+static int alloc_work(mcmc_hip_ctx* c, long long nP) {
+    /* history + LL scratch for nP lanes; contents are fully rewritten by every evaluation */
+    if (int r = c->dHn.alloc((size_t)c->histRows * nP)) return r;
+    if (int r = c->dHe.alloc((size_t)c->histRows * nP)) return r;
+    if (int r = c->dD1s.alloc((size_t)c->cfg.n_data * nP)) return r;
+    HIP_TRY(hipMemsetAsync(c->dHn.p, 0, c->dHn.n * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(c->dHe.p, 0, c->dHe.n * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(c->dD1s.p, 0, c->dD1s.n * sizeof(double), c->stream));
+    c->S.hn = c->dHn.p; c->S.he = c->dHe.p; c->S.d1s = c->dD1s.p;
+    return 0;
+}
+
+int mcmc_hip_set_chains(mcmc_hip_ctx* c, int64_t n_chains, const double* params, const double* stepsizes,
+                        const uint64_t* chain_ids, uint64_t first_chain_id) {
+    if (int r = check_ctx(c)) return r;
+    if (!c->haveTables || !c->haveData) return fail(MCMC_HIP_ESTATE, "set_chains: call set_tables and set_data first");
+    if (n_chains < 1 || !params) return fail(MCMC_HIP_EINVAL, "set_chains: need n_chains >= 1 and params");
+    HIP_TRY(hipSetDevice(c->device));
+    const long long n = n_chains;
+    const long long nP = (n + MCMC_WAVE - 1) / MCMC_WAVE * MCMC_WAVE;
+    const int dim = c->dim;
+    c->haveChains = false;
+    c->nChains = n; c->nP = nP; c->M.nP = nP;
+    if (int r = c->dParams.alloc((size_t)2 * dim * nP)) return r;
+    if (int r = c->dLL.alloc(2 * nP)) return r;
+    if (int r = c->dStepsize.alloc(nP)) return r;
+    if (int r = c->dRng.alloc(2 * nP)) return r;
+    if (int r = c->dNAccept.alloc(nP)) return r;
+    if (int r = c->dPairs.alloc(nP)) return r;
+    if (int r = c->dMean.alloc((size_t)dim * nP)) return r;
+    c->dRecLL.release(); c->dRecSamples.release();
+    c->nSaved = 0; c->nSavedCap = 0; c->recSamples = false;
+    ChainState& S = c->S;
+    S.params = c->dParams.p; S.prop = c->dParams.p + (size_t)dim * nP; S.ll = c->dLL.p; S.stepsize = c->dStepsize.p;
+    S.rng = c->dRng.p; S.nAccept = c->dNAccept.p; S.pairs = c->dPairs.p; S.mean = c->dMean.p;
+    S.recLL = nullptr; S.recSamples = nullptr; S.nChains = n; S.dim = dim;
+    if (int r = alloc_work(c, nP)) return r;
+
+    /* upload chain-major params and transpose to SoA on the device */
+    DevBuf<double> stage;
+    if (int r = stage.alloc((size_t)n * dim)) return r;
+    HIP_TRY(hipMemcpyAsync(stage.p, params, (size_t)n * dim * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const unsigned tb = 256, tg = (unsigned)((nP + tb - 1) / tb);
+    hipLaunchKernelGGL(transpose_in_kernel, dim3(tg), dim3(tb), 0, c->stream, (const double*)stage.p, S.params, n, dim, nP);
+    HIP_TRY(hipGetLastError());
+    /* MetropolisChain::mean starts as a deep copy of the state (mcmc.h:1002) */
+    HIP_TRY(hipMemcpyAsync(c->dMean.p, S.params, (size_t)dim * nP * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(S.params + (size_t)dim * nP, 0, (size_t)dim * nP * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(S.nAccept, 0, nP * sizeof(int), c->stream));
+    HIP_TRY(hipMemsetAsync(S.pairs, 0, nP * sizeof(unsigned long long), c->stream));
+
+    std::vector<double> ss(nP, 1.0);
+    std::vector<uint64_t> rng(2 * nP);
+    for (long long i = 0; i < nP; ++i) {
+        const long long src = i < n ? i : n - 1;
+        if (stepsizes) ss[i] = stepsizes[src];
+        const uint64_t id = chain_ids ? chain_ids[src] : first_chain_id + (uint64_t)src;
+        pcg32_seed(rng[i], rng[nP + i], 0, id);                      /* rnd(0, chainid), mcmc.h:999 */
+    }
+    HIP_TRY(hipMemcpyAsync(S.stepsize, ss.data(), nP * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(S.rng, rng.data(), 2 * nP * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    if (int r = run_eval_current(c)) return r;                       /* State::eval, mcmc.h:385-393 */
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->haveChains = true;
+    c->stepsDone = 0;
+    return 0;
+}
+
+int mcmc_hip_step(mcmc_hip_ctx* c, int32_t n_steps, double beta, int32_t random_subspace) {
+    if (int r = check_ctx(c)) return r;
+    if (!c->haveChains) return fail(MCMC_HIP_ESTATE, "step: call set_chains first");
+    if (n_steps < 0) return fail(MCMC_HIP_EINVAL, "step: n_steps < 0");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<double> betas(n_steps, beta);
+    std::vector<int> flags(n_steps, random_subspace ? SF_RANDOM : 0);
+    return run_schedule(c, betas, flags, 0, (size_t)n_steps, 32, nullptr);
+}
+
+int mcmc_hip_run(mcmc_hip_ctx* c, int32_t nSamples, int32_t nBurnin, int32_t nAdjust, int32_t thinning,
+                 int32_t record_samples, int32_t compute_mean) {
+    if (int r = check_ctx(c)) return r;
+    if (!c->haveChains) return fail(MCMC_HIP_ESTATE, "run: call set_chains first");
+    if (nSamples < 0 || nBurnin < 0 || nAdjust < 0 || thinning < 1)
+        return fail(MCMC_HIP_EINVAL, "run: need n_samples,n_burnin,n_adjust >= 0 and thinning >= 1");
+    HIP_TRY(hipSetDevice(c->device));
+    const long long nP = c->nP;
+    /* the step schedule of MetropolisChain::run (mcmc.h:1023-1127) */
+    std::vector<double> betas;
+    std::vector<int> flags;
+    betas.reserve((size_t)20 * nAdjust + nSamples);
+    flags.reserve((size_t)20 * nAdjust + nSamples);
+    size_t adjustEnd = 0;
+    bool first = true;
+    for (int i = 0; i < nSamples + nAdjust; ++i) {
+        int pre = 0;
+        if (first) { pre |= SF_RESET_ACC; first = false; }            /* int nAccept = 0, mcmc.h:1007 */
+        if (i == nAdjust) pre |= SF_RESET_ACC;                         /* mcmc.h:1032 */
+        if (i >= nBurnin && (i % thinning) == 0) pre |= SF_RECORD;     /* mcmc.h:1037 */
+        if (i > nBurnin && compute_mean) pre |= SF_MEAN;               /* mcmc.h:1064 */
+        if (i < nAdjust) {
+            const double b = target_beta(c->cfg, (double)i / nAdjust); /* mcmc.h:1091 */
+            for (int j = 0; j < 20; ++j) {                             /* nRepeat, mcmc.h:1096 */
+                int f = (j == 0) ? (pre | SF_RANDOM | SF_RESET_ACC) : 0;
+                if (j == 19) f |= SF_ADJUST_END;
+                betas.push_back(b);
+                flags.push_back(f);
+            }
+            adjustEnd = betas.size();
+        } else {
+            betas.push_back(target_beta(c->cfg, (double)(i - nAdjust) / nSamples)); /* mcmc.h:1126 */
+            flags.push_back(pre | SF_RANDOM);
+        }
+    }
+    const int nSaved = mcmc_hip_n_saved(nSamples, nBurnin, nAdjust, thinning);
+    c->nSaved = 0;
+    c->recSamples = record_samples != 0;
+    if (int r = c->dRecLL.alloc((size_t)std::max(nSaved, 1) * nP)) return r;
+    c->S.recLL = c->dRecLL.p;
+    if (record_samples) {
+        if (int r = c->dRecSamples.alloc((size_t)std::max(nSaved, 1) * c->dim * nP)) return r;
+        c->S.recSamples = c->dRecSamples.p;
+    } else {
+        c->dRecSamples.release();
+        c->S.recSamples = nullptr;
+    }
+    c->nSavedCap = nSaved;
+    c->S.mean = compute_mean ? c->dMean.p : nullptr;
+    c->adjustS = c->samplingS = c->kernelS = 0;
+    c->kernelLaunches = 0;
+    /* launches are cut so that a single kernel stays well below a second */
+    const int perLaunch = 20;
+    if (int r = run_schedule(c, betas, flags, 0, adjustEnd, perLaunch, &c->adjustS)) return r;
+    if (int r = run_schedule(c, betas, flags, adjustEnd, betas.size(), perLaunch, &c->samplingS)) return r;
+    if (compute_mean && nAdjust + nSamples - nBurnin != 0) {           /* mcmc.h:1133-1134 */
+        const long long count = (long long)c->dim * nP;
+        const double f = 1.0 / (double)(nAdjust + nSamples - nBurnin);
+        hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, c->dMean.p, count, f);
+        HIP_TRY(hipGetLastError());
+    }
+    c->S.mean = c->dMean.p;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->nSaved = nSaved;
+    return 0;
+}
+
+int mcmc_hip_dim(const mcmc_hip_ctx* c) { return c ? c->dim : MCMC_HIP_EINVAL; }
+int mcmc_hip_size(const mcmc_hip_ctx* c) { return c ? c->size : MCMC_HIP_EINVAL; }
+int64_t mcmc_hip_n_chains(const mcmc_hip_ctx* c) { return c ? c->nChains : MCMC_HIP_EINVAL; }
+
+}  /* extern "C" */
+
+/* copies a [rows][nP] SoA field out as [n][rows] */
+template <typename Tp>
+static int copy_field(mcmc_hip_ctx* c, const Tp* dev, int rows, Tp* out) {
+    const long long nP = c->nP, n = c->nChains;
+    std::vector<Tp> h((size_t)rows * nP);
+    HIP_TRY(hipMemcpy(h.data(), dev, h.size() * sizeof(Tp), hipMemcpyDeviceToHost));
+    for (long long i = 0; i < n; ++i)
+        for (int r = 0; r < rows; ++r) out[i * rows + r] = h[(size_t)r * nP + i];
+    return 0;
+}
+
+extern "C" {
+
+static int need_chains(mcmc_hip_ctx* c, const void* out) {
+    if (int r = check_ctx(c)) return r;
+    if (!c->haveChains) return fail(MCMC_HIP_ESTATE, "no chains: call set_chains first");
+    if (!out) return fail(MCMC_HIP_EINVAL, "null output buffer");
+    if (hipSetDevice(c->device) != hipSuccess) return fail(MCMC_HIP_EHIP, "hipSetDevice failed");
+    return 0;
+}
+
+static int gather_soa(mcmc_hip_ctx* c, const double* src, double* out) {
+    const long long n = c->nChains, nP = c->nP;
+    DevBuf<double> stage;
+    if (int r = stage.alloc((size_t)n * c->dim)) return r;
+    const unsigned tb = 256, tg = (unsigned)((n + tb - 1) / tb);
+    hipLaunchKernelGGL(transpose_out_kernel, dim3(tg), dim3(tb), 0, c->stream, src, stage.p, n, c->dim, nP);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, stage.p, (size_t)n * c->dim * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int mcmc_hip_get_params(mcmc_hip_ctx* c, double* out) {
+    if (int r = need_chains(c, out)) return r;
+    return gather_soa(c, c->S.params, out);
+}
+int mcmc_hip_get_loglike(mcmc_hip_ctx* c, double* out) {
+    if (int r = need_chains(c, out)) return r;
+    return copy_field<double>(c, c->S.ll, 2, out);
+}
+int mcmc_hip_get_stepsizes(mcmc_hip_ctx* c, double* out) {
+    if (int r = need_chains(c, out)) return r;
+    return copy_field<double>(c, c->S.stepsize, 1, out);
+}
+int mcmc_hip_get_accept_counts(mcmc_hip_ctx* c, int32_t* out) {
+    if (int r = need_chains(c, out)) return r;
+    return copy_field<int>(c, c->S.nAccept, 1, out);
+}
+int mcmc_hip_get_rng_state(mcmc_hip_ctx* c, uint64_t* out) {
+    if (int r = need_chains(c, out)) return r;
+    return copy_field<uint64_t>(c, c->S.rng, 2, out);
+}
+int mcmc_hip_get_loglikes(mcmc_hip_ctx* c, double* out) {
+    if (int r = need_chains(c, out)) return r;
+    if (c->nSaved == 0) return fail(MCMC_HIP_ESTATE, "Requested loglikes, but none are present");
+    return copy_field<double>(c, c->S.recLL, c->nSaved, out);
+}
+int mcmc_hip_get_samples(mcmc_hip_ctx* c, int64_t chain, int32_t coord_first, int32_t coord_count, double* out) {
+    if (int r = need_chains(c, out)) return r;
+    if (!c->recSamples || c->nSaved == 0) return fail(MCMC_HIP_ESTATE, "Requested samples, but none are present");
+    if (chain < 0 || chain >= c->nChains || coord_first < 0 || coord_count < 1 || coord_first + coord_count > c->dim)
+        return fail(MCMC_HIP_EINVAL, "get_samples: chain/coordinate range out of bounds");
+    const long long nP = c->nP;
+    /* strided device->host copy: element (s,k) sits at ((s*dim + k)*nP + chain) */
+    for (int s = 0; s < c->nSaved; ++s)
+        HIP_TRY(hipMemcpy2D(out + (size_t)s * coord_count, sizeof(double),
+                            c->S.recSamples + ((size_t)s * c->dim + coord_first) * nP + chain,
+                            (size_t)nP * sizeof(double), sizeof(double), coord_count, hipMemcpyDeviceToHost));
+    return 0;
+}
+int mcmc_hip_get_sample_all(mcmc_hip_ctx* c, int32_t saved_index, double* out) {
+    if (int r = need_chains(c, out)) return r;
+    if (!c->recSamples || saved_index < 0 || saved_index >= c->nSaved)
+        return fail(MCMC_HIP_EINVAL, "get_sample_all: no such saved sample");
+    return gather_soa(c, c->S.recSamples + (size_t)saved_index * c->dim * c->nP, out);
+}
+int mcmc_hip_get_mean(mcmc_hip_ctx* c, double* out) {
+    if (int r = need_chains(c, out)) return r;
+    return gather_soa(c, c->dMean.p, out);
+}
+
+/* shared by eval and derive: external vectors on their own lane set */
+static int with_external(mcmc_hip_ctx* c, int64_t n, const double* params, bool derive, double* out) {
+    if (int r = check_ctx(c)) return r;
+    if (!c->haveTables || !c->haveData) return fail(MCMC_HIP_ESTATE, "call set_tables and set_data first");
+    if (n < 1 || !params || !out) return fail(MCMC_HIP_EINVAL, "need n >= 1, params and an output buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    const long long nP = (n + MCMC_WAVE - 1) / MCMC_WAVE * MCMC_WAVE;
+    const int dim = c->dim;
+    /* a temporary lane set so that chain state is untouched */
+    mcmc_hip_ctx tmp;
+    tmp.cfg = c->cfg; tmp.device = c->device; tmp.stream = c->stream; tmp.size = c->size;
+    tmp.simPad = c->simPad; tmp.histRows = c->histRows; tmp.dim = dim; tmp.nP = nP; tmp.nChains = n;
+    tmp.M = c->M; tmp.M.nP = nP;
+    int rc = 0;
+    DevBuf<double> stage, soa, res;
+    do {
+        if ((rc = alloc_work(&tmp, nP))) break;
+        if ((rc = stage.alloc((size_t)n * dim))) break;
+        if ((rc = soa.alloc((size_t)dim * nP))) break;
+        if ((rc = res.alloc(derive ? (size_t)9 * c->size * nP : (size_t)2 * nP))) break;
+        tmp.S.dim = dim; tmp.S.nChains = n;
+        hipError_t e = hipMemcpyAsync(stage.p, params, (size_t)n * dim * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { rc = fail(MCMC_HIP_EHIP, "upload failed: %s", hipGetErrorString(e)); break; }
+        const unsigned tb = 256, tg = (unsigned)((nP + tb - 1) / tb);
+        hipLaunchKernelGGL(transpose_in_kernel, dim3(tg), dim3(tb), 0, c->stream, (const double*)stage.p, soa.p, (long long)n, dim, nP);
+        if (derive) {
+            if (c->cfg.contract) rc = launch_chain_kernel(&tmp, derive_kernel<MCMC_T_DERIVE, true>, tmp.M, tmp.S, (const double*)soa.p, res.p, tmp.simPad);
+            else rc = launch_chain_kernel(&tmp, derive_kernel<MCMC_T_DERIVE, false>, tmp.M, tmp.S, (const double*)soa.p, res.p, tmp.simPad);
+        } else {
+            if (c->cfg.contract) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true>, tmp.M, tmp.S, (const double*)soa.p, res.p, tmp.simPad);
+            else rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, false>, tmp.M, tmp.S, (const double*)soa.p, res.p, tmp.simPad);
+        }
+        if (rc) break;
+        const int rows = derive ? 9 * c->size : 2;
+        std::vector<double> h((size_t)rows * nP);
+        e = hipMemcpyAsync(h.data(), res.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { rc = fail(MCMC_HIP_EHIP, "kernel or download failed: %s", hipGetErrorString(e)); break; }
+        for (long long i = 0; i < n; ++i)
+            for (int r = 0; r < rows; ++r) out[i * rows + r] = h[(size_t)r * nP + i];
+    } while (0);
+    tmp.stream = nullptr;      /* borrowed */
+    return rc;
+}
+
+int mcmc_hip_eval(mcmc_hip_ctx* c, int64_t n, const double* params, double* ll_out) {
+    return with_external(c, n, params, false, ll_out);
+}
+int mcmc_hip_derive(mcmc_hip_ctx* c, int64_t n, const double* params, double* curves_out) {
+    return with_external(c, n, params, true, curves_out);
+}
+
+int mcmc_hip_diagnostics(mcmc_hip_ctx* c, double* out) {
+    if (int r = need_chains(c, out)) return r;
+    const int len = 4 + 2 * c->dim;
+    DevBuf<double> d;
+    if (int r = d.alloc(len)) return r;
+    HIP_TRY(hipMemsetAsync(d.p, 0, len * sizeof(double), c->stream));
+    hipLaunchKernelGGL(diagnostics_kernel, dim3((unsigned)(c->nP / MCMC_WAVE)), dim3(MCMC_WAVE), 0, c->stream, c->M, c->S, d.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d.p, len * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    out[1] = (double)c->stepsDone;
+    return 0;
+}
+
+int mcmc_hip_last_timing(mcmc_hip_ctx* c, double* adjust_s, double* sampling_s, double* step_kernel_s,
+                         int64_t* step_kernel_launches) {
+    if (int r = check_ctx(c)) return r;
+    if (adjust_s) *adjust_s = c->adjustS;
+    if (sampling_s) *sampling_s = c->samplingS;
+    if (step_kernel_s) *step_kernel_s = c->kernelS;
+    if (step_kernel_launches) *step_kernel_launches = c->kernelLaunches;
+    return 0;
+}
+
+int mcmc_hip_pair_count(mcmc_hip_ctx* c, double* pairs_out, int32_t reset) {
+    if (int r = need_chains(c, pairs_out)) return r;
+    std::vector<unsigned long long> h(c->nP);
+    HIP_TRY(hipMemcpy(h.data(), c->S.pairs, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double s = 0;
+    for (long long i = 0; i < c->nChains; ++i) s += (double)h[i];
+    *pairs_out = s;
+    if (reset) HIP_TRY(hipMemset(c->S.pairs, 0, h.size() * sizeof(unsigned long long)));
+    return 0;
+}
+
+}  // extern "C"

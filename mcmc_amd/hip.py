@@ -1,0 +1,256 @@
+"""ctypes view of the C ABI in include/mcmc_hip.h (libmcmc_hip.so).
+
+This is the only way Python reaches the hot path; there is no CPU fallback.  If the
+library is missing or no GPU is visible the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import covid_config as CC
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcmc_hip.so")
+
+NCURVES = 10
+OUT_CURVES = ["mildlyInfectious", "highlyInfectious", "incubating", "asymptomatic", "mild",
+              "serious", "recovered", "dead", "totalBehavior"]
+
+# every symbol include/mcmc_hip.h declares
+SYMBOLS = [
+    "mcmc_hip_last_error", "mcmc_hip_device_count", "mcmc_host_make_response_tables",
+    "mcmc_host_default_disease_params", "mcmc_host_perturb_ics", "mcmc_hip_create",
+    "mcmc_hip_destroy", "mcmc_hip_set_tables", "mcmc_hip_set_data", "mcmc_hip_set_chains",
+    "mcmc_hip_run", "mcmc_hip_step", "mcmc_hip_n_saved", "mcmc_hip_dim", "mcmc_hip_size",
+    "mcmc_hip_n_chains", "mcmc_hip_get_params", "mcmc_hip_get_loglike", "mcmc_hip_get_stepsizes",
+    "mcmc_hip_get_accept_counts", "mcmc_hip_get_rng_state", "mcmc_hip_get_loglikes",
+    "mcmc_hip_get_samples", "mcmc_hip_get_sample_all", "mcmc_hip_get_mean", "mcmc_hip_eval",
+    "mcmc_hip_derive", "mcmc_hip_diagnostics", "mcmc_hip_last_timing", "mcmc_hip_pair_count",
+]
+
+
+class McmcHipError(RuntimeError):
+    pass
+
+
+class DiseaseParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in CC.PARAM_FIELDS]
+
+
+class CovidConfig(C.Structure):
+    _fields_ = [
+        ("n_data", C.c_int32), ("max_delay", C.c_int32), ("n_predict", C.c_int32),
+        ("n_disc", C.c_int32), ("fix_behavior_in_advance", C.c_int32), ("pop_size", C.c_int32),
+        ("prob_icu_if_serious", C.c_double), ("prob_lethal_daily_untreated", C.c_double),
+        ("cap0", C.c_double), ("cap_incr_rate", C.c_double),
+        ("has_prior", C.c_int32), ("smooth_Ls", C.c_double), ("smooth_L", C.c_double),
+        ("target_kind", C.c_int32), ("target_T", C.c_double), ("target_slope", C.c_double),
+        ("target_Tinit", C.c_double), ("contract", C.c_int32),
+        ("disc_days", C.POINTER(C.c_int32)), ("disc_fixed", C.POINTER(C.c_uint8)),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load libmcmc_hip.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise McmcHipError(f"{LIB_PATH} not found: build it with `make -C mcmc_amd/csrc` "
+                           "(or __graft_entry__.build()); the hot path has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    vp = C.c_void_p
+    L.mcmc_hip_last_error.restype = C.c_char_p
+    L.mcmc_hip_device_count.restype = C.c_int
+    L.mcmc_host_make_response_tables.argtypes = [C.POINTER(DiseaseParams), C.c_uint64, C.c_int32, dp]
+    L.mcmc_host_default_disease_params.argtypes = [C.POINTER(DiseaseParams)]
+    L.mcmc_host_default_disease_params.restype = None
+    L.mcmc_host_perturb_ics.argtypes = [dp, C.c_int32, C.c_int64, C.c_double, C.c_uint64, C.c_uint64, dp]
+    L.mcmc_hip_create.argtypes = [C.POINTER(CovidConfig), C.c_int, C.POINTER(vp)]
+    L.mcmc_hip_destroy.argtypes = [vp]
+    L.mcmc_hip_set_tables.argtypes = [vp, dp, C.c_int32]
+    L.mcmc_hip_set_data.argtypes = [vp, dp, dp]
+    L.mcmc_hip_set_chains.argtypes = [vp, C.c_int64, dp, dp, C.POINTER(C.c_uint64), C.c_uint64]
+    L.mcmc_hip_run.argtypes = [vp] + [C.c_int32] * 6
+    L.mcmc_hip_step.argtypes = [vp, C.c_int32, C.c_double, C.c_int32]
+    L.mcmc_hip_n_saved.argtypes = [C.c_int32] * 4
+    L.mcmc_hip_n_saved.restype = C.c_int32
+    L.mcmc_hip_dim.argtypes = [vp]
+    L.mcmc_hip_size.argtypes = [vp]
+    L.mcmc_hip_n_chains.argtypes = [vp]
+    L.mcmc_hip_n_chains.restype = C.c_int64
+    for name in ("get_params", "get_loglike", "get_stepsizes", "get_loglikes", "get_mean", "diagnostics"):
+        getattr(L, "mcmc_hip_" + name).argtypes = [vp, dp]
+    L.mcmc_hip_get_accept_counts.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.mcmc_hip_get_rng_state.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.mcmc_hip_get_samples.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, dp]
+    L.mcmc_hip_get_sample_all.argtypes = [vp, C.c_int32, dp]
+    L.mcmc_hip_eval.argtypes = [vp, C.c_int64, dp, dp]
+    L.mcmc_hip_derive.argtypes = [vp, C.c_int64, dp, dp]
+    L.mcmc_hip_last_timing.argtypes = [vp, dp, dp, dp, C.POINTER(C.c_int64)]
+    L.mcmc_hip_pair_count.argtypes = [vp, dp, C.c_int32]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise McmcHipError(f"mcmc_hip error {rc}: {lib().mcmc_hip_last_error().decode()}")
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+_KIND = {"plain": 0, "temp": 1, "cooling": 2}
+
+
+def make_response_tables(disease_params: dict, n_traj=10_000_000, n_lag=500):
+    """AvgDiseaseTrajectory (covid.h:96-282) -> R[10][n_lag]; host precompute as in the
+    reference."""
+    p = DiseaseParams(**{k: float(disease_params[k]) for k in CC.PARAM_FIELDS})
+    R = np.zeros((NCURVES, n_lag), dtype=np.float64)
+    _check(lib().mcmc_host_make_response_tables(C.byref(p), n_traj, n_lag, _dp(R)))
+    return R
+
+
+def perturb_ics(x0, n_chains, a=0.01, initstate=0, initseq=0):
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    out = np.zeros((n_chains, x0.size), dtype=np.float64)
+    _check(lib().mcmc_host_perturb_ics(_dp(x0), x0.size, n_chains, a, initstate, initseq, _dp(out)))
+    return out
+
+
+class CovidSampler:
+    """Owns one mcmc_hip_ctx: the GPU-resident replacement of
+    ChainManager<MetropolisChain> + DiseaseSpread + SmoothnessPrior + Target for the covid
+    model (mcmc.h:1314-1655, covid.h:284-662)."""
+
+    def __init__(self, cfg: dict, R, device=0):
+        L = lib()
+        self.cfg = cfg
+        self._disc_days = np.ascontiguousarray(cfg["disc_days"], dtype=np.int32)
+        self._disc_fixed = np.ascontiguousarray(cfg["disc_fixed"], dtype=np.uint8)
+        c = CovidConfig()
+        for k in ("n_data", "max_delay", "n_predict", "n_disc", "fix_behavior_in_advance", "pop_size",
+                  "has_prior", "contract"):
+            setattr(c, k, int(cfg[k]))
+        for k in ("prob_icu_if_serious", "prob_lethal_daily_untreated", "cap0", "cap_incr_rate",
+                  "smooth_Ls", "smooth_L", "target_T", "target_slope", "target_Tinit"):
+            setattr(c, k, float(cfg[k]))
+        c.target_kind = _KIND[cfg["target_kind"]]
+        c.disc_days = self._disc_days.ctypes.data_as(C.POINTER(C.c_int32))
+        c.disc_fixed = self._disc_fixed.ctypes.data_as(C.POINTER(C.c_uint8))
+        self._h = C.c_void_p()
+        _check(L.mcmc_hip_create(C.byref(c), device, C.byref(self._h)))
+        R = np.ascontiguousarray(R, dtype=np.float64)
+        assert R.ndim == 2 and R.shape[0] == NCURVES
+        _check(L.mcmc_hip_set_tables(self._h, _dp(R), R.shape[1]))
+        deaths = np.ascontiguousarray(cfg["deaths"], dtype=np.float64)
+        sigma = np.ascontiguousarray(cfg["sigma"], dtype=np.float64)
+        _check(L.mcmc_hip_set_data(self._h, _dp(deaths), _dp(sigma)))
+        self.dim = L.mcmc_hip_dim(self._h)
+        self.size = L.mcmc_hip_size(self._h)
+        self.n_chains = 0
+        self.n_saved = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().mcmc_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- chains -------------------------------------------------------------------------
+    def set_chains(self, params, stepsizes=None, chain_ids=None, first_chain_id=1):
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        assert params.ndim == 2 and params.shape[1] == self.dim, (params.shape, self.dim)
+        n = params.shape[0]
+        ss = None if stepsizes is None else np.ascontiguousarray(
+            np.broadcast_to(stepsizes, (n,)), dtype=np.float64)
+        ids = None if chain_ids is None else np.ascontiguousarray(chain_ids, dtype=np.uint64)
+        _check(lib().mcmc_hip_set_chains(
+            self._h, n, _dp(params), _dp(ss),
+            ids.ctypes.data_as(C.POINTER(C.c_uint64)) if ids is not None else None, first_chain_id))
+        self.n_chains = n
+
+    def run(self, n_samples, n_burnin, n_adjust, thinning, record_samples=False, compute_mean=False):
+        _check(lib().mcmc_hip_run(self._h, n_samples, n_burnin, n_adjust, thinning,
+                                  int(record_samples), int(compute_mean)))
+        self.n_saved = lib().mcmc_hip_n_saved(n_samples, n_burnin, n_adjust, thinning)
+
+    def step(self, n_steps, beta=1.0, random_subspace=True):
+        _check(lib().mcmc_hip_step(self._h, n_steps, beta, int(random_subspace)))
+
+    # --- results ------------------------------------------------------------------------
+    def _get(self, name, shape, dtype=np.float64, ctype=C.c_double):
+        out = np.zeros(shape, dtype=dtype)
+        _check(getattr(lib(), "mcmc_hip_" + name)(self._h, out.ctypes.data_as(C.POINTER(ctype))))
+        return out
+
+    def params(self):
+        return self._get("get_params", (self.n_chains, self.dim))
+
+    def loglike(self):
+        return self._get("get_loglike", (self.n_chains, 2))
+
+    def stepsizes(self):
+        return self._get("get_stepsizes", (self.n_chains,))
+
+    def accept_counts(self):
+        return self._get("get_accept_counts", (self.n_chains,), np.int32, C.c_int32)
+
+    def rng_state(self):
+        return self._get("get_rng_state", (self.n_chains, 2), np.uint64, C.c_uint64)
+
+    def loglikes(self):
+        return self._get("get_loglikes", (self.n_chains, self.n_saved))
+
+    def mean(self):
+        return self._get("get_mean", (self.n_chains, self.dim))
+
+    def samples(self, chain, coord_first=0, coord_count=None):
+        coord_count = self.dim - coord_first if coord_count is None else coord_count
+        out = np.zeros((self.n_saved, coord_count))
+        _check(lib().mcmc_hip_get_samples(self._h, chain, coord_first, coord_count, _dp(out)))
+        return out
+
+    def sample_all(self, saved_index):
+        out = np.zeros((self.n_chains, self.dim))
+        _check(lib().mcmc_hip_get_sample_all(self._h, saved_index, _dp(out)))
+        return out
+
+    def eval(self, params):
+        params = np.ascontiguousarray(np.atleast_2d(params), dtype=np.float64)
+        out = np.zeros((params.shape[0], 2))
+        _check(lib().mcmc_hip_eval(self._h, params.shape[0], _dp(params), _dp(out)))
+        return out
+
+    def derive(self, params):
+        params = np.ascontiguousarray(np.atleast_2d(params), dtype=np.float64)
+        out = np.zeros((params.shape[0], 9, self.size))
+        _check(lib().mcmc_hip_derive(self._h, params.shape[0], _dp(params), _dp(out)))
+        return out
+
+    def diagnostics(self):
+        return self._get("diagnostics", (4 + 2 * self.dim,))
+
+    def last_timing(self):
+        a, s, k = C.c_double(), C.c_double(), C.c_double()
+        n = C.c_int64()
+        _check(lib().mcmc_hip_last_timing(self._h, C.byref(a), C.byref(s), C.byref(k), C.byref(n)))
+        return dict(adjust_s=a.value, sampling_s=s.value, step_kernel_s=k.value, launches=n.value)
+
+    def pair_count(self, reset=False):
+        v = C.c_double()
+        _check(lib().mcmc_hip_pair_count(self._h, C.byref(v), int(reset)))
+        return v.value
