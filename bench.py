@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Metropolis-Hastings steps/s on the covid model.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one Target::step (mcmc.h:750-783) for EVERY chain of the workload: proposal,
+compartment-model forward simulation, likelihood, prior, accept/reject.  Workload =
+BASELINE.json configs[2]: covid.h model, 65536 independent chains PER GPU, 365-day synthetic
+series, chain-sharded by chain-id range (weak scaling, no collective on the data path).
+All inputs are resident in HBM before the timed region.  Arithmetic is FP64 as in the
+reference (`using Float = double`, mcmc.h:43).
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mcmc_amd import covid_config as CC  # noqa: E402
+from mcmc_amd import hip as H  # noqa: E402
+
+PEAK_FP64_VECTOR_TFLOPS = 78.6      # MI355X FP64 vector (FMA = 2 flop): 256 CU x 4 SIMD x 16 lanes/clk x 2 x 2.4 GHz
+PEAK_FP32_VECTOR_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (vector)"
+N_DATA = 365
+CHAINS_PER_GPU = 65536
+BETA_MILD, BETA_HIGH = 0.8, 2.5     # SURVEY 8d's (2, 10) overflow to NaN in the forward model
+
+
+def build_workload(device, n_chains, first_chain_id, contract, n_data=N_DATA):
+    """Synthetic inputs per SURVEY 8(d): response table by the host precompute, counts by the
+    forward model at the initial parameters, sigma by the notebook's recipe, chains = initial
+    parameters perturbed by +-1 % (pcg32(0,0)), chain ids first_chain_id.."""
+    dp = CC.ipynb_disease_params()
+    R = H.make_response_tables(dp)                       # host, 10M trajectories, a few seconds
+    probe_holder = {}
+
+    def forward(cfg, x):
+        s = H.CovidSampler(cfg, R, device)
+        dead = s.derive(x[None, :])[0, 7]
+        s.close()
+        probe_holder["ok"] = True
+        return dead
+
+    cfg = CC.synthetic_config(n_data, forward, disease_params=dp, initial_beta_mild=BETA_MILD,
+                              initial_beta_high=BETA_HIGH, contract=contract)
+    x0 = CC.initial_params(cfg)
+    # one global IC stream so that chain i has the same start on any sharding
+    xs_all = H.perturb_ics(x0, first_chain_id - 1 + n_chains, 0.01)
+    xs = xs_all[first_chain_id - 1:]
+    sampler = H.CovidSampler(cfg, R, device)
+    sampler.set_chains(xs, first_chain_id=first_chain_id)
+    return cfg, R, xs, sampler
+
+
+def cpu_baseline(cfg, R10, xs, contract, seconds=15.0):
+    """The oracle (a CPU port of the same path, oracle/mcmc_oracle.c) timed on this box's
+    host cores on a bounded sample of the same workload.  Reported, not the target."""
+    from oracle import oracle as O
+    # ABI curve order -> oracle's 11-curve order (asymptomatic unused by the model)
+    R11 = np.zeros((O.NCURVES, R10.shape[1]))
+    for k, c in enumerate([3, 4, 0, 2, 5, 7, 6, 8, 9, 10]):
+        R11[c] = R10[k]
+    m = O.Model(cfg, R11, contract=contract)
+    tgt = O.make_target("temp", 1.0)
+    threads = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 64))
+    n_chains = 4 * threads
+    cal = O.run_chains(m, tgt, xs[:n_chains], 1.0, 4, 0, 0, 1000, n_threads=threads)
+    per_step = cal["wall"] / 4
+    n_samples = int(max(8, min(4000, seconds / max(per_step, 1e-6))))
+    res = O.run_chains(m, tgt, xs[:n_chains], 1.0, n_samples, 0, 0, 1000, n_threads=threads)
+    return {"value": res["steps"] / res["wall"], "unit": "MH steps/s", "cores": threads, "kind": "port",
+            "sample": f"{n_chains} chains x {n_samples} steps of the same 365-day workload "
+                      f"(oracle/mcmc_oracle.c, lean table, {threads} pthreads, {res['wall']:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU)
+    ap.add_argument("--contract", type=int, default=int(os.environ.get("MCMC_BENCH_CONTRACT", "1")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = local_rank if world > 1 else 0
+    if H.lib().mcmc_hip_device_count() < 1:
+        raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
+
+    n_chains = args.chains_per_gpu
+    first_id = 1 + rank * n_chains                       # contiguous chain-id ranges
+    cfg, R, xs, s = build_workload(device, n_chains, first_id, args.contract)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    s.step(args.warmup, 1.0, True)
+    s.pair_count(reset=True)
+    t_before = s.last_timing()
+    sync()
+    t0 = time.perf_counter()
+    s.step(args.steps, 1.0, True)                        # the library syncs its stream per launch
+    sync()
+    dt = time.perf_counter() - t0
+    t_after = s.last_timing()
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        total_steps = world * n_chains * args.steps
+        value = total_steps / dt
+        # roofline of the dominant kernel (mh_step_kernel) on this rank
+        ksec = t_after["step_kernel_s"] - t_before["step_kernel_s"]
+        launches = t_after["launches"] - t_before["launches"]
+        pairs = s.pair_count()                            # sum over chains/steps, SURVEY 8d work unit
+        nB = cfg["nB"]
+        flops = 16.0 * pairs + (10.0 * N_DATA + 7.0 * nB) * n_chains * args.steps
+        achieved = flops / ksec / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MH steps/sec (whole node) on covid model, 64k chains",
+            "value": value, "unit": "MH steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "covid.h model, 65536 independent chains per GPU, 365-day synthetic "
+                                   "series, chain-sharded (BASELINE.json configs[2])",
+                       "chains_per_gpu": n_chains, "n_data": N_DATA, "dim": cfg["dim"],
+                       "size": cfg["size"], "fp_contract": "fma" if args.contract else "strict",
+                       "parallelism": f"chain-shard x{world}"},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP64_VECTOR_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VECTOR_TFLOPS,
+                         "traffic": traffic, "kernel": "mh_step_kernel",
+                         "kernel_ms_per_launch": 1e3 * ksec / max(launches, 1), "launches": launches,
+                         "steps_per_launch": args.steps / max(launches, 1),
+                         "algorithmic_flops_per_launch": flops / max(launches, 1),
+                         "frac_of_fp32_vector_peak": achieved / PEAK_FP32_VECTOR_TFLOPS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(cfg, R, xs, args.contract)
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = value / cb["value"]
+        print(json.dumps(out), flush=True)
+    s.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

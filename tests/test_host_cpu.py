@@ -1,0 +1,151 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol,
+host precompute matches the oracle, sharding + diagnostics reduce correctly (gloo, 2 ranks).
+No device compute is attempted here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ABI_CURVE_ORDER, ROOT, make_cfg, perturbed
+from mcmc_amd import covid_config as CC, hip as H, sharding as SH
+from oracle import oracle as O
+
+
+def test_library_exports_every_symbol_the_header_declares():
+    hdr = open(os.path.join(ROOT, "include", "mcmc_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(mcmc_(?:hip|host)_\w+)\s*\(", hdr)))
+    assert sorted(H.SYMBOLS) == declared
+    L = H.lib()
+    for sym in declared:
+        assert getattr(L, sym) is not None
+
+
+def test_create_fails_loudly_without_a_gpu_or_with_bad_arguments(R11):
+    L = H.lib()
+    cfg = make_cfg(40, R11, max_delay=12, n_predict=5, fix_behavior_in_advance=5, initial_delay=7.0)
+    if L.mcmc_hip_device_count() == 0:
+        with pytest.raises(H.McmcHipError, match="no HIP device"):
+            H.CovidSampler(cfg, R11[ABI_CURVE_ORDER])
+    bad = dict(cfg); bad["n_disc"] = 0
+    with pytest.raises(H.McmcHipError):
+        H.CovidSampler(bad, R11[ABI_CURVE_ORDER])
+    h = C.c_void_p()
+    assert L.mcmc_hip_create(None, 0, C.byref(h)) == -1 and b"null" in L.mcmc_hip_last_error()
+    assert L.mcmc_hip_run(None, 1, 0, 0, 1, 0, 0) == -1
+    assert L.mcmc_hip_destroy(None) == 0
+
+
+def test_host_response_table_equals_oracle_bitwise():
+    dp = CC.ipynb_disease_params()
+    R = H.make_response_tables(dp, n_traj=300_000, n_lag=500)
+    grid = O.traj_generate(O.DiseaseParams(**dp), 300_000)
+    Ro = O.traj_response(grid)
+    assert np.array_equal(R, Ro[ABI_CURVE_ORDER])
+    # a cumulative outcome curve ends near its probability mass
+    assert abs(R[6, 499] - dp["probLethal"]) < 2e-3            # dead
+    assert abs(R[7, 0] - 1.0) < 1e-12                           # seriousFromSerious starts at 1
+
+
+def test_default_disease_params_match_covid_h():
+    p = H.DiseaseParams()
+    H.lib().mcmc_host_default_disease_params(C.byref(p))
+    for k, v in CC.DISEASE_PARAMS_DEFAULT.items():
+        assert getattr(p, k) == v
+
+
+def test_perturb_ics_follows_state_perturb_rule(R11):
+    cfg = make_cfg(40, R11, max_delay=12, n_predict=5, fix_behavior_in_advance=5, initial_delay=7.0)
+    x0 = CC.initial_params(cfg)
+    got = H.perturb_ics(x0, 5, 0.05)
+    assert np.array_equal(got, perturbed(cfg, 5, 0.05))
+
+
+def test_n_saved_matches_run_loop():
+    L = H.lib()
+    for (ns, nb, na, th) in [(2000, 0, 200, 50), (30, 2, 4, 3), (0, 0, 40, 1), (10, 50, 0, 1), (7, 0, 0, 100)]:
+        want = len([i for i in range(ns + na) if i >= nb and i % th == 0])
+        assert L.mcmc_hip_n_saved(ns, nb, na, th) == want == O.lib().orc_n_saved(ns, nb, na, th)
+
+
+def test_config_layout(R11):
+    cfg = make_cfg(200, R11)
+    assert cfg["size"] == 300 and cfg["nB"] == 186 and cfg["dim"] == 193
+    cfg = CC.make_config(np.zeros(365), np.ones(365))
+    assert cfg["size"] == 465 and cfg["nB"] == 351 and cfg["dim"] == 358      # C3
+    x = CC.initial_params(cfg)
+    assert x.shape == (358,) and x[-1] == 23.0 and x[-3] == 2.0
+    s = CC.sigma_recipe(CC.ITALY_DEATHS)
+    assert s[0] == 10 + 1 and s[20] == 140 + np.sqrt(827)
+
+
+def test_shard_ranges_partition_the_chains():
+    for n, w in [(65536, 8), (1000, 3), (7, 8), (64, 1)]:
+        got = [SH.shard_range(n, r, w) for r in range(w)]
+        assert got[0][0] == 0 and got[-1][1] == n
+        assert all(got[i][1] == got[i + 1][0] for i in range(w - 1))
+        ids = np.concatenate([SH.shard_chain_ids(n, r, w) for r in range(w)])
+        assert np.array_equal(ids, np.arange(1, n + 1, dtype=np.uint64))     # ids i+1, mcmc.h:1527
+
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch.distributed as dist
+from conftest import make_cfg, perturbed
+from mcmc_amd import sharding as SH
+from oracle import oracle as O
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+R11 = np.load(os.path.join(sys.argv[1], "tests", "golden", "R_ipynb_oracle.npy"))
+cfg = make_cfg(40, R11, max_delay=12, n_predict=5, fix_behavior_in_advance=5, initial_delay=7.0)
+m = O.Model(cfg, R11)
+N = 6
+xs = perturbed(cfg, N, 0.05)
+lo, hi = SH.shard_range(N, rank, world)
+tgt = O.make_target("temp", 1.0)
+samples = []
+for i in range(lo, hi):
+    ch = O.OracleChain(m, i + 1, xs[i])
+    ll, s, _ = ch.run(tgt, 40, 0, 2, 2)
+    samples.append(s[:, -3:])
+sums = SH.allreduce_sum(SH.moment_sums(np.array(samples), max_lag=4))
+if rank == 0:
+    json.dump({"sums": sums.tolist(), "n_saved": int(np.array(samples).shape[1])}, open(sys.argv[2], "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_sharding_gives_single_process_diagnostics(tmp_path, R11):
+    """world_size=2 over gloo: each rank runs its chain-id range, the additive diagnostics
+    vector is all-reduced; result must equal the unsharded computation."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = tmp_path / "out.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), ROOT, str(out)]
+    subprocess.run(cmd, check=True, env=env, timeout=300, capture_output=True)
+    import json
+    got = json.load(open(out))
+    cfg = make_cfg(40, R11, max_delay=12, n_predict=5, fix_behavior_in_advance=5, initial_delay=7.0)
+    m = O.Model(cfg, R11)
+    xs = perturbed(cfg, 6, 0.05)
+    tgt = O.make_target("temp", 1.0)
+    samples = []
+    for i in range(6):
+        ch = O.OracleChain(m, i + 1, xs[i])
+        samples.append(ch.run(tgt, 40, 0, 2, 2)[1][:, -3:])
+    samples = np.array(samples)
+    want = SH.moment_sums(samples, max_lag=4)
+    sums = np.array(got["sums"])
+    assert sums[0] == 6
+    assert np.allclose(sums[2:], want[2:], rtol=1e-12, atol=1e-12)
+    rhat, ess = SH.rhat_ess(sums, 3, got["n_saved"], max_lag=4)
+    rhat1, ess1 = SH.rhat_ess(want, 3, samples.shape[1], max_lag=4)
+    assert np.allclose(rhat, rhat1, equal_nan=True) and np.allclose(ess, ess1)
