@@ -84,8 +84,8 @@ def cpu_baseline(cfg, R10, xs, contract, seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU)
     ap.add_argument("--contract", type=int, default=int(os.environ.get("MCMC_BENCH_CONTRACT", "1")))
     ap.add_argument("--no-cpu-baseline", action="store_true")

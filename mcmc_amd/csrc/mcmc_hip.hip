@@ -20,6 +20,9 @@
 #ifndef MCMC_T
 #define MCMC_T 8           /* days per register block, see mcmc_kernels.hip.h */
 #endif
+#ifndef MCMC_STEPS_PER_LAUNCH
+#define MCMC_STEPS_PER_LAUNCH 16   /* MH steps one mh_step_kernel launch advances every chain by */
+#endif
 #ifndef MCMC_T_DERIVE
 #define MCMC_T_DERIVE 4    /* the derive kernel is not a hot path: small block, short compile */
 #endif
@@ -528,7 +531,7 @@ int mcmc_hip_step(mcmc_hip_ctx* c, int32_t n_steps, double beta, int32_t random_
     HIP_TRY(hipSetDevice(c->device));
     std::vector<double> betas(n_steps, beta);
     std::vector<int> flags(n_steps, random_subspace ? SF_RANDOM : 0);
-    return run_schedule(c, betas, flags, 0, (size_t)n_steps, 32, nullptr);
+    return run_schedule(c, betas, flags, 0, (size_t)n_steps, MCMC_STEPS_PER_LAUNCH, nullptr);
 }
 
 int mcmc_hip_run(mcmc_hip_ctx* c, int32_t nSamples, int32_t nBurnin, int32_t nAdjust, int32_t thinning,
@@ -583,7 +586,7 @@ int mcmc_hip_run(mcmc_hip_ctx* c, int32_t nSamples, int32_t nBurnin, int32_t nAd
     c->adjustS = c->samplingS = c->kernelS = 0;
     c->kernelLaunches = 0;
     /* launches are cut so that a single kernel stays well below a second */
-    const int perLaunch = 20;
+    const int perLaunch = MCMC_STEPS_PER_LAUNCH;
     if (int r = run_schedule(c, betas, flags, 0, adjustEnd, perLaunch, &c->adjustS)) return r;
     if (int r = run_schedule(c, betas, flags, adjustEnd, betas.size(), perLaunch, &c->samplingS)) return r;
     if (compute_mean && nAdjust + nSamples - nBurnin != 0) {           /* mcmc.h:1133-1134 */
