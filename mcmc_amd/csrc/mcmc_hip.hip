@@ -78,7 +78,8 @@ struct mcmc_hip_ctx {
     bool haveTables = false, haveData = false, haveChains = false;
     DevModel M{};
     ChainState S{};
-    long long nChains = 0, nP = 0;
+    long long nChains = 0, nP = 0;      /* nP = nTiles*64 */
+    int nTiles = 0;
     int nSaved = 0, nSavedCap = 0;
     bool recSamples = false;
     /* model constants */
@@ -220,24 +221,36 @@ double target_beta(const mcmc_covid_config& c, double time) {
     }
 }
 
+/* One workgroup = 4 waves = 4 chain tiles sharing one LDS image (table + series).  With at
+ * most one workgroup per CU's worth of tiles the LDS request is padded past half the CU's
+ * 160 KB so that the dispatcher cannot stack two workgroups on one CU while another idles. */
+constexpr size_t kLdsMax = 160 * 1024;
+constexpr size_t kLdsSolo = 81 * 1024;
+
 template <typename K, typename... Args>
-int launch_chain_kernel(mcmc_hip_ctx* c, K kernel, Args... args) {
-    const unsigned grid = (unsigned)(c->nP / MCMC_WAVE);
-    const size_t shmem = lds_bytes(c->simPad, c->cfg.n_data);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(MCMC_WAVE), shmem, c->stream, args...);
+int launch_chain_kernel(mcmc_hip_ctx* c, K kernel, bool derive, int T, Args... args) {
+    const unsigned grid = (unsigned)((c->nTiles + MCMC_WAVES_PER_BLOCK - 1) / MCMC_WAVES_PER_BLOCK);
+    size_t shmem = lds_bytes(c->M, derive, T);
+    if (shmem > kLdsMax)
+        return fail(MCMC_HIP_EINVAL, "the series is too long for the LDS image (%zu B > %zu B)", shmem, kLdsMax);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    if (grid <= (unsigned)prop.multiProcessorCount && shmem < kLdsSolo) shmem = kLdsSolo;
+    HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(MCMC_BLOCK), shmem, c->stream, args...);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int run_eval_current(mcmc_hip_ctx* c) {
-    if (c->cfg.contract) return launch_chain_kernel(c, eval_kernel<MCMC_T, true>, c->M, c->S, (const double*)c->S.params, c->S.ll, c->simPad);
-    return launch_chain_kernel(c, eval_kernel<MCMC_T, false>, c->M, c->S, (const double*)c->S.params, c->S.ll, c->simPad);
+    if (c->cfg.contract) return launch_chain_kernel(c, eval_kernel<MCMC_T, true>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
+    return launch_chain_kernel(c, eval_kernel<MCMC_T, false>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
 }
 
 int launch_steps(mcmc_hip_ctx* c, int nSteps, const double* dBetas, const int* dFlags, int slot0) {
     if (c->cfg.contract)
-        return launch_chain_kernel(c, mh_step_kernel<MCMC_T, true>, c->M, c->S, nSteps, dBetas, dFlags, slot0, c->simPad);
-    return launch_chain_kernel(c, mh_step_kernel<MCMC_T, false>, c->M, c->S, nSteps, dBetas, dFlags, slot0, c->simPad);
+        return launch_chain_kernel(c, mh_step_kernel<MCMC_T, true>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0);
+    return launch_chain_kernel(c, mh_step_kernel<MCMC_T, false>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0);
 }
 
 int check_ctx(const mcmc_hip_ctx* c) {
@@ -396,6 +409,7 @@ int mcmc_hip_create(const mcmc_covid_config* cfg, int device, mcmc_hip_ctx** out
     DevModel& M = c->M;
     M.nData = cfg->n_data; M.md = md; M.size = c->size; M.nB = c->nB; M.nDisc = nD;
     M.simDays = c->simDays; M.nLagRows = c->nLag; M.hasPrior = cfg->has_prior ? 1 : 0;
+    M.tabRows = c->tabRows; M.simPad = c->simPad;
     M.pop = (double)cfg->pop_size; M.probICU = cfg->prob_icu_if_serious;
     M.probLethal = cfg->prob_lethal_daily_untreated;
     M.smoothLs = cfg->smooth_Ls; M.smoothL = cfg->smooth_L; M.dNData = (double)cfg->n_data;
@@ -460,11 +474,12 @@ static int alloc_work(mcmc_hip_ctx* c, long long nP) {
     /* history + LL scratch for nP lanes; contents are fully rewritten by every evaluation */
     if (int r = c->dHn.alloc((size_t)c->histRows * nP)) return r;
     if (int r = c->dHe.alloc((size_t)c->histRows * nP)) return r;
-    if (int r = c->dD1s.alloc((size_t)c->cfg.n_data * nP)) return r;
+    if (int r = c->dD1s.alloc((size_t)2 * c->cfg.n_data * nP)) return r;
     HIP_TRY(hipMemsetAsync(c->dHn.p, 0, c->dHn.n * sizeof(double), c->stream));
     HIP_TRY(hipMemsetAsync(c->dHe.p, 0, c->dHe.n * sizeof(double), c->stream));
     HIP_TRY(hipMemsetAsync(c->dD1s.p, 0, c->dD1s.n * sizeof(double), c->stream));
     c->S.hn = c->dHn.p; c->S.he = c->dHe.p; c->S.d1s = c->dD1s.p;
+    c->S.histRows = c->histRows; c->S.nTiles = (int)(nP / MCMC_WAVE);
     return 0;
 }
 
@@ -478,7 +493,7 @@ int mcmc_hip_set_chains(mcmc_hip_ctx* c, int64_t n_chains, const double* params,
     const long long nP = (n + MCMC_WAVE - 1) / MCMC_WAVE * MCMC_WAVE;
     const int dim = c->dim;
     c->haveChains = false;
-    c->nChains = n; c->nP = nP; c->M.nP = nP;
+    c->nChains = n; c->nP = nP; c->nTiles = (int)(nP / MCMC_WAVE);
     if (int r = c->dParams.alloc((size_t)2 * dim * nP)) return r;
     if (int r = c->dLL.alloc(2 * nP)) return r;
     if (int r = c->dStepsize.alloc(nP)) return r;
@@ -499,7 +514,7 @@ int mcmc_hip_set_chains(mcmc_hip_ctx* c, int64_t n_chains, const double* params,
     if (int r = stage.alloc((size_t)n * dim)) return r;
     HIP_TRY(hipMemcpyAsync(stage.p, params, (size_t)n * dim * sizeof(double), hipMemcpyHostToDevice, c->stream));
     const unsigned tb = 256, tg = (unsigned)((nP + tb - 1) / tb);
-    hipLaunchKernelGGL(transpose_in_kernel, dim3(tg), dim3(tb), 0, c->stream, (const double*)stage.p, S.params, n, dim, nP);
+    hipLaunchKernelGGL(tile_in_kernel<double>, dim3(tg), dim3(tb), 0, c->stream, (const double*)stage.p, S.params, n, dim, nP);
     HIP_TRY(hipGetLastError());
     /* MetropolisChain::mean starts as a deep copy of the state (mcmc.h:1002) */
     HIP_TRY(hipMemcpyAsync(c->dMean.p, S.params, (size_t)dim * nP * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -513,7 +528,8 @@ int mcmc_hip_set_chains(mcmc_hip_ctx* c, int64_t n_chains, const double* params,
         const long long src = i < n ? i : n - 1;
         if (stepsizes) ss[i] = stepsizes[src];
         const uint64_t id = chain_ids ? chain_ids[src] : first_chain_id + (uint64_t)src;
-        pcg32_seed(rng[i], rng[nP + i], 0, id);                      /* rnd(0, chainid), mcmc.h:999 */
+        const size_t t0 = (size_t)(i / MCMC_WAVE) * 2 * MCMC_WAVE + (size_t)(i % MCMC_WAVE);
+        pcg32_seed(rng[t0], rng[t0 + MCMC_WAVE], 0, id);             /* rnd(0, chainid), mcmc.h:999 */
     }
     HIP_TRY(hipMemcpyAsync(S.stepsize, ss.data(), nP * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(S.rng, rng.data(), 2 * nP * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
@@ -607,9 +623,20 @@ int64_t mcmc_hip_n_chains(const mcmc_hip_ctx* c) { return c ? c->nChains : MCMC_
 
 }  /* extern "C" */
 
-/* copies a [rows][nP] SoA field out as [n][rows] */
+/* copies a tile-major [nTiles][rows][64] field out as [n][rows] */
 template <typename Tp>
 static int copy_field(mcmc_hip_ctx* c, const Tp* dev, int rows, Tp* out) {
+    const long long nP = c->nP, n = c->nChains;
+    std::vector<Tp> h((size_t)rows * nP);
+    HIP_TRY(hipMemcpy(h.data(), dev, h.size() * sizeof(Tp), hipMemcpyDeviceToHost));
+    for (long long i = 0; i < n; ++i)
+        for (int r = 0; r < rows; ++r)
+            out[i * rows + r] = h[((size_t)(i / MCMC_WAVE) * rows + r) * MCMC_WAVE + (size_t)(i % MCMC_WAVE)];
+    return 0;
+}
+/* copies a flat [rows][nP] field out as [n][rows] */
+template <typename Tp>
+static int copy_rows(mcmc_hip_ctx* c, const Tp* dev, int rows, Tp* out) {
     const long long nP = c->nP, n = c->nChains;
     std::vector<Tp> h((size_t)rows * nP);
     HIP_TRY(hipMemcpy(h.data(), dev, h.size() * sizeof(Tp), hipMemcpyDeviceToHost));
@@ -629,11 +656,11 @@ static int need_chains(mcmc_hip_ctx* c, const void* out) {
 }
 
 static int gather_soa(mcmc_hip_ctx* c, const double* src, double* out) {
-    const long long n = c->nChains, nP = c->nP;
+    const long long n = c->nChains;
     DevBuf<double> stage;
     if (int r = stage.alloc((size_t)n * c->dim)) return r;
     const unsigned tb = 256, tg = (unsigned)((n + tb - 1) / tb);
-    hipLaunchKernelGGL(transpose_out_kernel, dim3(tg), dim3(tb), 0, c->stream, src, stage.p, n, c->dim, nP);
+    hipLaunchKernelGGL(tile_out_kernel<double>, dim3(tg), dim3(tb), 0, c->stream, src, stage.p, n, c->dim);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, stage.p, (size_t)n * c->dim * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -663,19 +690,19 @@ int mcmc_hip_get_rng_state(mcmc_hip_ctx* c, uint64_t* out) {
 int mcmc_hip_get_loglikes(mcmc_hip_ctx* c, double* out) {
     if (int r = need_chains(c, out)) return r;
     if (c->nSaved == 0) return fail(MCMC_HIP_ESTATE, "Requested loglikes, but none are present");
-    return copy_field<double>(c, c->S.recLL, c->nSaved, out);
+    return copy_rows<double>(c, c->S.recLL, c->nSaved, out);
 }
 int mcmc_hip_get_samples(mcmc_hip_ctx* c, int64_t chain, int32_t coord_first, int32_t coord_count, double* out) {
     if (int r = need_chains(c, out)) return r;
     if (!c->recSamples || c->nSaved == 0) return fail(MCMC_HIP_ESTATE, "Requested samples, but none are present");
     if (chain < 0 || chain >= c->nChains || coord_first < 0 || coord_count < 1 || coord_first + coord_count > c->dim)
         return fail(MCMC_HIP_EINVAL, "get_samples: chain/coordinate range out of bounds");
-    const long long nP = c->nP;
-    /* strided device->host copy: element (s,k) sits at ((s*dim + k)*nP + chain) */
+    const size_t tile = (size_t)(chain / MCMC_WAVE), lane = (size_t)(chain % MCMC_WAVE);
+    /* strided device->host copy: element (s,k) sits at ((s*nTiles + tile)*dim + k)*64 + lane */
     for (int s = 0; s < c->nSaved; ++s)
         HIP_TRY(hipMemcpy2D(out + (size_t)s * coord_count, sizeof(double),
-                            c->S.recSamples + ((size_t)s * c->dim + coord_first) * nP + chain,
-                            (size_t)nP * sizeof(double), sizeof(double), coord_count, hipMemcpyDeviceToHost));
+                            c->S.recSamples + (((size_t)s * c->nTiles + tile) * c->dim + coord_first) * MCMC_WAVE + lane,
+                            (size_t)MCMC_WAVE * sizeof(double), sizeof(double), coord_count, hipMemcpyDeviceToHost));
     return 0;
 }
 int mcmc_hip_get_sample_all(mcmc_hip_ctx* c, int32_t saved_index, double* out) {
@@ -701,7 +728,7 @@ static int with_external(mcmc_hip_ctx* c, int64_t n, const double* params, bool 
     mcmc_hip_ctx tmp;
     tmp.cfg = c->cfg; tmp.device = c->device; tmp.stream = c->stream; tmp.size = c->size;
     tmp.simPad = c->simPad; tmp.histRows = c->histRows; tmp.dim = dim; tmp.nP = nP; tmp.nChains = n;
-    tmp.M = c->M; tmp.M.nP = nP;
+    tmp.M = c->M; tmp.nTiles = (int)(nP / MCMC_WAVE);
     int rc = 0;
     DevBuf<double> stage, soa, res;
     do {
@@ -713,13 +740,13 @@ static int with_external(mcmc_hip_ctx* c, int64_t n, const double* params, bool 
         hipError_t e = hipMemcpyAsync(stage.p, params, (size_t)n * dim * sizeof(double), hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) { rc = fail(MCMC_HIP_EHIP, "upload failed: %s", hipGetErrorString(e)); break; }
         const unsigned tb = 256, tg = (unsigned)((nP + tb - 1) / tb);
-        hipLaunchKernelGGL(transpose_in_kernel, dim3(tg), dim3(tb), 0, c->stream, (const double*)stage.p, soa.p, (long long)n, dim, nP);
+        hipLaunchKernelGGL(tile_in_kernel<double>, dim3(tg), dim3(tb), 0, c->stream, (const double*)stage.p, soa.p, (long long)n, dim, nP);
         if (derive) {
-            if (c->cfg.contract) rc = launch_chain_kernel(&tmp, derive_kernel<MCMC_T_DERIVE, true>, tmp.M, tmp.S, (const double*)soa.p, res.p, tmp.simPad);
-            else rc = launch_chain_kernel(&tmp, derive_kernel<MCMC_T_DERIVE, false>, tmp.M, tmp.S, (const double*)soa.p, res.p, tmp.simPad);
+            if (c->cfg.contract) rc = launch_chain_kernel(&tmp, derive_kernel<MCMC_T_DERIVE, true>, true, MCMC_T_DERIVE, tmp.M, tmp.S, (const double*)soa.p, res.p);
+            else rc = launch_chain_kernel(&tmp, derive_kernel<MCMC_T_DERIVE, false>, true, MCMC_T_DERIVE, tmp.M, tmp.S, (const double*)soa.p, res.p);
         } else {
-            if (c->cfg.contract) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true>, tmp.M, tmp.S, (const double*)soa.p, res.p, tmp.simPad);
-            else rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, false>, tmp.M, tmp.S, (const double*)soa.p, res.p, tmp.simPad);
+            if (c->cfg.contract) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
+            else rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, false>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
         }
         if (rc) break;
         const int rows = derive ? 9 * c->size : 2;
@@ -728,7 +755,8 @@ static int with_external(mcmc_hip_ctx* c, int64_t n, const double* params, bool 
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { rc = fail(MCMC_HIP_EHIP, "kernel or download failed: %s", hipGetErrorString(e)); break; }
         for (long long i = 0; i < n; ++i)
-            for (int r = 0; r < rows; ++r) out[i * rows + r] = h[(size_t)r * nP + i];
+            for (int r = 0; r < rows; ++r)
+                out[i * rows + r] = h[((size_t)(i / MCMC_WAVE) * rows + r) * MCMC_WAVE + (size_t)(i % MCMC_WAVE)];
     } while (0);
     tmp.stream = nullptr;      /* borrowed */
     return rc;
@@ -747,7 +775,7 @@ int mcmc_hip_diagnostics(mcmc_hip_ctx* c, double* out) {
     DevBuf<double> d;
     if (int r = d.alloc(len)) return r;
     HIP_TRY(hipMemsetAsync(d.p, 0, len * sizeof(double), c->stream));
-    hipLaunchKernelGGL(diagnostics_kernel, dim3((unsigned)(c->nP / MCMC_WAVE)), dim3(MCMC_WAVE), 0, c->stream, c->M, c->S, d.p);
+    hipLaunchKernelGGL(diagnostics_kernel, dim3((unsigned)c->nTiles), dim3(MCMC_WAVE), 0, c->stream, c->M, c->S, d.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d.p, len * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

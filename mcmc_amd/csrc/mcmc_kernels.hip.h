@@ -47,27 +47,22 @@
 
 #define MCMC_MAXDISC 8
 #define MCMC_WAVE 64
+#define MCMC_WAVES_PER_BLOCK 4     /* one wave per SIMD of a CU share one LDS image */
 
-/* constant address space: loads through it are invariant, so a wave-uniform address
- * becomes an s_load (scalar cache -> SGPR) instead of a per-lane vector load. */
-typedef const double __attribute__((address_space(4))) cdouble_t;
-typedef const int __attribute__((address_space(4))) cint_t;
 typedef double double8_t __attribute__((ext_vector_type(8)));
 typedef double double4_t __attribute__((ext_vector_type(4)));
-typedef const double8_t __attribute__((address_space(4))) cdouble8_t;
-typedef const double4_t __attribute__((address_space(4))) cdouble4_t;
 
 /* accumulator families */
 enum { A_MI = 0, A_HI, A_INC, A_MILD, A_SER, A_REC, A_DEAD, A_NPOS };
 
 struct DevModel {
     int nData, md, size, nB, nDisc, simDays, nLagRows, hasPrior;
-    long long nP;                 /* padded chain count = SoA stride                  */
+    int tabRows, simPad;
     double pop, probICU, probLethal, smoothLs, smoothL, dNData;
     float discThr;                /* 2/nNotFixed, float division done on the host    */
     unsigned discFixedMask;
-    const double* Rpos;           /* [nLagRows][8]: MI HI INC MILD SER REC DEAD 0    */
-    const double* Rneg;           /* [nLagRows][4]: SFS RFS DFS 0                    */
+    const double* Rpos;           /* [tabRows][8]: MI HI INC MILD SER REC DEAD 0; rows >= nLagRows zero */
+    const double* Rneg;           /* [tabRows][4]: SFS RFS DFS 0                     */
     const double* capacity;       /* [simPad]                                        */
     const double* deaths;         /* [nData]                                         */
     const double* sigma2;         /* [nData]  sigma[i]*sigma[i] (covid.h:491)        */
@@ -123,31 +118,51 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
     return __builtin_amdgcn_readfirstlane(v);
 }
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return __builtin_amdgcn_readfirstlane(v);
-}
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 
-/* LDS image of the observed series and the per-day constants, staged once per block */
+/*
+ * LDS image, staged ONCE per workgroup and shared by its four waves: the response table
+ * (what the phase-A inner loop multiplies with) and the observed series / per-day
+ * constants.  The table rows are wave-uniform reads: every lane of a wave reads the same
+ * address, which the LDS serves as a broadcast.
+ */
 struct LdsView {
+    const double* Rpos;       /* [ldsRows][8] */
+    const double* Rneg;       /* [ldsRows][4] */
     const double* capacity;   /* [simPad] */
     const double* deaths;     /* [nData]  */
     const double* sigma2;     /* [nData]  */
     const int* seg;           /* [simPad] */
 };
 
-__device__ inline LdsView stage_lds(const DevModel& M, double* lds, int simPad) {
-    double* cap = lds;
-    double* dea = cap + simPad;
+__host__ __device__ inline int lds_rows(const DevModel& M, bool derive, int T) {
+    /* lags reach horizon+T-2; rows >= nLagRows are zero and a chunk made only of them is
+     * skipped, so nothing above row nLagRows+T-2 is ever read */
+    const int h = derive ? M.size : M.simDays;
+    const int a = h + 2 * T, b = M.nLagRows + T;
+    const int r = a < b ? a : b;
+    return r < M.tabRows ? r : M.tabRows;
+}
+__host__ __device__ inline size_t lds_bytes(const DevModel& M, bool derive, int T) {
+    return sizeof(double) * ((size_t)12 * lds_rows(M, derive, T) + (size_t)M.simPad + 2 * (size_t)M.nData) +
+           sizeof(int) * (size_t)M.simPad + 16;
+}
+
+__device__ inline LdsView stage_lds(const DevModel& M, double* lds, bool derive, int T) {
+    const int rows = lds_rows(M, derive, T);
+    double* rp = lds;
+    double* rn = rp + (size_t)8 * rows;
+    double* cap = rn + (size_t)4 * rows;
+    double* dea = cap + M.simPad;
     double* sg2 = dea + M.nData;
     int* seg = (int*)(sg2 + M.nData);
-    for (int i = threadIdx.x; i < simPad; i += blockDim.x) {
+    for (int i = threadIdx.x; i < 8 * rows; i += blockDim.x) rp[i] = M.Rpos[i];
+    for (int i = threadIdx.x; i < 4 * rows; i += blockDim.x) rn[i] = M.Rneg[i];
+    for (int i = threadIdx.x; i < M.simPad; i += blockDim.x) {
         cap[i] = M.capacity[i];
         seg[i] = M.seg[i];
     }
@@ -157,26 +172,27 @@ __device__ inline LdsView stage_lds(const DevModel& M, double* lds, int simPad) 
     }
     __syncthreads();
     LdsView v;
-    v.capacity = cap; v.deaths = dea; v.sigma2 = sg2; v.seg = seg;
+    v.Rpos = rp; v.Rneg = rn; v.capacity = cap; v.deaths = dea; v.sigma2 = sg2; v.seg = seg;
     return v;
-}
-__host__ __device__ inline size_t lds_bytes(int simPad, int nData) {
-    return sizeof(double) * ((size_t)simPad + 2 * (size_t)nData) + sizeof(int) * (size_t)simPad + 8;
 }
 
 /*
- * Addressing convention.  Every per-chain array is SoA [row][nP].  A wave addresses it as
- * (uniform base + uniform row offset)[lane]: the row part stays in SGPRs and the lane part
- * is ONE shared 32-bit VGPR offset, so a load/store costs no address arithmetic on the
- * vector ALU and no address registers (global_load ... v_off, s[base:base+1]).
- * All `*_u` pointers below are wave-uniform and already advanced to the wave's first chain.
+ * Addressing convention.  Chains are grouped in TILES of 64 (one wave).  Every per-chain
+ * array is tile-major: element (row, chain) of an array with `rows` rows lives at
+ *     base[((chain/64) * rows + row) * 64 + chain%64]
+ * so that (a) each access of a wave is one contiguous 512-byte line and (b) everything one
+ * wave ever touches of an array is ONE contiguous block (a 405-day infection history is
+ * 207 KB per wave instead of 405 lines 512 KB apart), which keeps it inside a handful of
+ * pages for the TLBs.  All `*_u` pointers below are wave-uniform and already advanced to
+ * the wave's tile; the lane part is the single 32-bit index `lane`.
  */
 struct WaveBases {
-    const double* x_u;     /* parameter vector being evaluated, element k at x_u[k*nP + lane] */
-    double* hn_u;          /* infection history,  day k at hn_u[(k+HOFF)*nP + lane]             */
+    const double* x_u;     /* parameter vector being evaluated, element k at x_u[k*64 + lane]  */
+    double* hn_u;          /* infection history,  day k at hn_u[(k+HOFF)*64 + lane]             */
     double* he_u;          /* extra-deaths history, same indexing                               */
-    double* d1s_u;         /* shift-1 weighted deaths of data day i at d1s_u[i*nP + lane]       */
-    double* curves_u;      /* DERIVE only: curve c, day i at curves_u[(c*size+i)*nP + lane]     */
+    double* d1s_u;         /* weighted deaths of data day i: first pass at d1s_u[i*64 + lane],
+                              second pass at d1s_u[(nData+i)*64 + lane]                         */
+    double* curves_u;      /* DERIVE only: curve c, day i at curves_u[(c*size+i)*64 + lane]     */
 };
 
 /* the scalars of a parameter vector that the day loop needs all the time */
@@ -184,22 +200,27 @@ struct LaneScalars {
     double betaMild, betaHigh, delay;
 };
 
+__device__ __forceinline__ double8_t lds_row8(const double* Rpos, int L) {
+    return *(const double8_t*)(Rpos + (size_t)L * 8);
+}
+__device__ __forceinline__ double4_t lds_row4(const double* Rneg, int L) {
+    return *(const double4_t*)(Rneg + (size_t)L * 4);
+}
+
 /* ------------------------------------------------------- phase A building blocks ---- */
 /* One chunk = T consecutive lags Lc, Lc-1, ..., Lc-T+1 applied to the T days of the block.
  * History window: element q in [0, 2T-1) is W[q] for q < T and N[q-T] otherwise, holding
  * n[kbase + q].  After step u the slot W[u] is dead and is refilled with the history value
  * 2T further on (it becomes the `N` of the chunk after next: ping-pong, no register moves).
- * WITH_E adds the capacity corrections of covid.h:416-429 from the e-history. */
-template <int T, bool FUSE, bool WITH_E>
-__device__ __forceinline__ void lag_chunk(double (&acc)[A_NPOS][T], double (&W)[T], double (&N)[T],
-                                          cdouble8_t* Rpos, cdouble4_t* Rneg, int Lc,
-                                          const double* hn_next_u, const double* he_k0_u,
-                                          long long nP, unsigned lane) {
+ * `r` carries the table row of the chunk's first lag in and that of the next chunk out, so
+ * the LDS read of a row is always issued one full step (56 multiply-adds) ahead of use. */
+template <int T, bool FUSE>
+__device__ __forceinline__ void lag_chunk(double (&acc)[A_NPOS][T], double (&W)[T], const double (&N)[T],
+                                          double8_t& r, const double* Rpos, int Lc,
+                                          const double* hn_next_u, unsigned lane) {
 #pragma unroll
     for (int u = 0; u < T; ++u) {
-        const double8_t r = Rpos[Lc - u];
-        double4_t rn;
-        if constexpr (WITH_E) rn = Rneg[Lc - u];
+        const double8_t rnext = lds_row8(Rpos, Lc - u - 1);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int q = t + u;
@@ -211,33 +232,59 @@ __device__ __forceinline__ void lag_chunk(double (&acc)[A_NPOS][T], double (&W)[
             acc[A_SER][t] = madd<FUSE>(nk, r[4], acc[A_SER][t]);
             acc[A_REC][t] = madd<FUSE>(nk, r[5], acc[A_REC][t]);
             acc[A_DEAD][t] = madd<FUSE>(nk, r[6], acc[A_DEAD][t]);
-            if constexpr (WITH_E) {
-                /* rare path (only source days with hospital overflow): no register window,
-                 * the e-history is re-read (L1/L2-resident) */
-                const double ek = (he_k0_u + (long long)q * nP)[lane];
-                const double nek = -ek;
-                acc[A_DEAD][t] = acc[A_DEAD][t] + ek;                       /* add(), covid.h:418 */
-                acc[A_SER][t] = madd<FUSE>(nek, rn[0], acc[A_SER][t]);      /* covid.h:426 */
-                acc[A_REC][t] = madd<FUSE>(nek, rn[1], acc[A_REC][t]);      /* covid.h:427 */
-                acc[A_DEAD][t] = madd<FUSE>(nek, rn[2], acc[A_DEAD][t]);    /* covid.h:428 */
-            }
         }
         /* slot u of W is dead from here on: prefetch for the chunk after next */
-        W[u] = (hn_next_u + (long long)u * nP)[lane];
+        W[u] = hn_next_u[u * MCMC_WAVE + lane];
+        r = rnext;
+    }
+}
+
+/* The same chunk when some source day of it carries a hospital-capacity correction e_k
+ * (covid.h:416-429): after the eight projections of day k come add(e_k) and the three
+ * negative projections, in that order.  Rarer path, kept small: the e-history is re-read
+ * where it is needed (L1-resident) instead of holding a second register window. */
+template <int T, bool FUSE>
+__device__ __forceinline__ void lag_chunk_e(double (&acc)[A_NPOS][T], double (&W)[T], const double (&N)[T],
+                                            double8_t& r, const double* Rpos, const double* Rneg, int Lc,
+                                            const double* hn_next_u, const double* he_k0_u, unsigned lane) {
+#pragma unroll
+    for (int u = 0; u < T; ++u) {
+        const double8_t rnext = lds_row8(Rpos, Lc - u - 1);
+        const double4_t rn = lds_row4(Rneg, Lc - u);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int q = t + u;
+            const double nk = (q < T) ? W[q < T ? q : 0] : N[q < T ? 0 : q - T];
+            acc[A_MI][t] = madd<FUSE>(nk, r[0], acc[A_MI][t]);
+            acc[A_HI][t] = madd<FUSE>(nk, r[1], acc[A_HI][t]);
+            acc[A_INC][t] = madd<FUSE>(nk, r[2], acc[A_INC][t]);
+            acc[A_MILD][t] = madd<FUSE>(nk, r[3], acc[A_MILD][t]);
+            acc[A_SER][t] = madd<FUSE>(nk, r[4], acc[A_SER][t]);
+            acc[A_REC][t] = madd<FUSE>(nk, r[5], acc[A_REC][t]);
+            acc[A_DEAD][t] = madd<FUSE>(nk, r[6], acc[A_DEAD][t]);
+            const double ek = he_k0_u[q * MCMC_WAVE + lane];
+            const double nek = -ek;
+            acc[A_DEAD][t] = acc[A_DEAD][t] + ek;                       /* add(), covid.h:418 */
+            acc[A_SER][t] = madd<FUSE>(nek, rn[0], acc[A_SER][t]);      /* covid.h:426 */
+            acc[A_REC][t] = madd<FUSE>(nek, rn[1], acc[A_REC][t]);      /* covid.h:427 */
+            acc[A_DEAD][t] = madd<FUSE>(nek, rn[2], acc[A_DEAD][t]);    /* covid.h:428 */
+        }
+        W[u] = hn_next_u[u * MCMC_WAVE + lane];
+        r = rnext;
     }
 }
 
 /* the lags T-1 .. 1: only destinations t < L have their source day before the block */
 template <int T, bool FUSE, bool WITH_E>
 __device__ __forceinline__ void lag_tail(double (&acc)[A_NPOS][T], const double (&W)[T],
-                                         cdouble8_t* Rpos, cdouble4_t* Rneg, const double* he_k0_u,
-                                         long long nP, unsigned lane) {
+                                         const double* Rpos, const double* Rneg, const double* he_k0_u,
+                                         unsigned lane) {
 #pragma unroll
     for (int v = 1; v < T; ++v) {
         const int L = T - v;
-        const double8_t r = Rpos[L];
+        const double8_t r = lds_row8(Rpos, L);
         double4_t rn;
-        if constexpr (WITH_E) rn = Rneg[L];
+        if constexpr (WITH_E) rn = lds_row4(Rneg, L);
 #pragma unroll
         for (int t = 0; t < L; ++t) {
             const double nk = W[t + v - 1];
@@ -249,7 +296,7 @@ __device__ __forceinline__ void lag_tail(double (&acc)[A_NPOS][T], const double 
             acc[A_REC][t] = madd<FUSE>(nk, r[5], acc[A_REC][t]);
             acc[A_DEAD][t] = madd<FUSE>(nk, r[6], acc[A_DEAD][t]);
             if constexpr (WITH_E) {
-                const double ek = (he_k0_u + (long long)(t + v - 1) * nP)[lane];
+                const double ek = he_k0_u[(t + v - 1) * MCMC_WAVE + lane];
                 const double nek = -ek;
                 acc[A_DEAD][t] = acc[A_DEAD][t] + ek;
                 acc[A_SER][t] = madd<FUSE>(nek, rn[0], acc[A_SER][t]);
@@ -269,16 +316,11 @@ __device__ __forceinline__ void lag_tail(double (&acc)[A_NPOS][T], const double 
  * full horizon `size` (the SURVEY 8d work unit).
  */
 template <int T, bool FUSE, bool DERIVE>
-__device__ double eval_model(const DevModel& M, const LdsView& lds, const WaveBases& B,
-                             const LaneScalars& lp, unsigned lane, unsigned long long& pairs) {
-    const long long nP = M.nP;
+__device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& lds, const WaveBases& B,
+                                             const LaneScalars& lp, unsigned lane, unsigned long long& pairs) {
     const int md = M.md;
     const int horizon = DERIVE ? M.size : M.simDays;
-    cdouble8_t* Rpos = (cdouble8_t*)M.Rpos;
-    cdouble4_t* Rneg = (cdouble4_t*)M.Rneg;
-    cdouble_t* Rp = (cdouble_t*)M.Rpos;      /* lag 0 .. T-1, used inside a block */
-    cdouble_t* Rn = (cdouble_t*)M.Rneg;
-    const double* xdisc_u = B.x_u + (long long)M.nB * nP;
+    const double* xdisc_u = B.x_u + M.nB * MCMC_WAVE;
 
     double loglike = 0;                                             /* covid.h:329 */
     int start = (int)((double)md - lp.delay);                       /* covid.h:331 */
@@ -303,11 +345,11 @@ __device__ double eval_model(const DevModel& M, const LdsView& lds, const WaveBa
          * patient zero (covid.h:339): n_s = 1, n_k = 0 for k < s */
 #pragma unroll 1
         for (int k = ws - 2 * T; k < ws; ++k) {
-            (B.hn_u + (long long)(k + MCMC_HOFF(T)) * nP)[lane] = 0.0;
-            (B.he_u + (long long)(k + MCMC_HOFF(T)) * nP)[lane] = 0.0;
+            B.hn_u[(k + MCMC_HOFF(T)) * MCMC_WAVE + lane] = 0.0;
+            B.he_u[(k + MCMC_HOFF(T)) * MCMC_WAVE + lane] = 0.0;
         }
         double ncur = (s == ws) ? 1.0 : 0.0;
-        (B.hn_u + (long long)(ws + MCMC_HOFF(T)) * nP)[lane] = ncur;
+        B.hn_u[(ws + MCMC_HOFF(T)) * MCMC_WAVE + lane] = ncur;
 
         if constexpr (DERIVE) {
             /* days before the wave's first start: all buffers are zero there */
@@ -315,12 +357,27 @@ __device__ double eval_model(const DevModel& M, const LdsView& lds, const WaveBa
             for (int i = 0; i < ws; ++i) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    double* o = B.curves_u + ((long long)c * M.size + i) * nP;
+                    double* o = B.curves_u + ((size_t)c * M.size + i) * MCMC_WAVE;
                     if (shift == 1) o[lane] = w * 0.0; else o[lane] += w * 0.0;
                 }
-                (B.curves_u + ((long long)8 * M.size + i) * nP)[lane] = 1.0; /* covid.h:349 */
+                B.curves_u[((size_t)8 * M.size + i) * MCMC_WAVE + lane] = 1.0; /* covid.h:349 */
             }
         }
+
+        /* the window of the first chunk is the same for every block of this shift: history
+         * rows a0 .. a0+2T-1 with a0 = ws-T+1 */
+        const int a0 = ws - T + 1;
+        const double* hbase = B.hn_u + (a0 + MCMC_HOFF(T)) * MCMC_WAVE;
+        const double* ebase = B.he_u + (a0 + MCMC_HOFF(T)) * MCMC_WAVE;
+        double WA[T], WB[T];
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+            WA[q] = hbase[q * MCMC_WAVE + lane];
+            WB[q] = hbase[(q + T) * MCMC_WAVE + lane];
+        }
+        int segCur = -2;
+        double pcfCur = 1.0;
+        double* ds_u = B.d1s_u + (shift == 1 ? 0 : M.nData * MCMC_WAVE);
 
 #pragma unroll 1
         for (int j0 = ws; j0 < horizon; j0 += T) {
@@ -330,62 +387,80 @@ __device__ double eval_model(const DevModel& M, const LdsView& lds, const WaveBa
 #pragma unroll
                 for (int t = 0; t < T; ++t) acc[c][t] = 0.0;
 
+            double beh[T];
             /* ------------- phase A: sources k < j0, lags descending = k ascending */
             const int b = (j0 - ws) / T;                     /* full chunks of T lags */
-            {
-                double WA[T], WB[T];
-                const int a0 = ws - T + 1;                   /* k of window element 0 */
-                const double* hbase = B.hn_u + (long long)(a0 + MCMC_HOFF(T)) * nP;
-                const double* ebase = B.he_u + (long long)(a0 + MCMC_HOFF(T)) * nP;
-                const bool anyE = keHi >= keLo;
+            const bool anyE = keHi >= keLo;
+            int Lc = j0 - ws + T - 1;                        /* first lag of chunk 0 */
+            int c0 = 0;
+            /* lags >= nLagRows are rows of zeros (the d < nDays cut-off of project(),
+             * covid.h:378): chunks made only of them are skipped, the window starts later */
+            if (Lc - T + 1 >= M.nLagRows) {
+                c0 = (Lc - T + 1 - M.nLagRows) / T + 1;
+                if (c0 > b) c0 = b;
+                Lc -= c0 * T;
 #pragma unroll
                 for (int q = 0; q < T; ++q) {
-                    WA[q] = (hbase + (long long)q * nP)[lane];
-                    WB[q] = (hbase + (long long)(q + T) * nP)[lane];
+                    WA[q] = hbase[(c0 * T + q) * MCMC_WAVE + lane];
+                    WB[q] = hbase[(c0 * T + q + T) * MCMC_WAVE + lane];
                 }
-                int cb = 0;
-                int Lc = j0 - ws + T - 1;
-                /* chunk c covers source days [a0+c*T, a0+c*T+2T-2] */
-                auto chunk_has_e = [&](int c) {
-                    const int klo = a0 + c * T, khi = klo + 2 * T - 2;
-                    return anyE && klo <= keHi && khi >= keLo;
-                };
-                /* lags >= nLag (500, covid.h:378) carry R = 0 rows: chunks made only of them
-                 * just keep the window sliding */
+            }
+            double8_t r = lds_row8(lds.Rpos, Lc);
+            const double* hnx = hbase + (c0 + 2) * T * MCMC_WAVE;   /* refill source of chunk c0 */
+            int nch = b - c0;
+            if (!anyE) {
+                /* the common case: two chunks per iteration, the window halves swap roles */
 #pragma unroll 1
-                while (cb + 2 <= b) {
-                    const double* hnx = hbase + (long long)(cb + 2) * T * nP;
-                    const double* ek0 = ebase + (long long)cb * T * nP;
-                    if (Lc - T + 1 < M.nLagRows) {
-                        if (chunk_has_e(cb)) lag_chunk<T, FUSE, true>(acc, WA, WB, Rpos, Rneg, Lc, hnx, ek0, nP, lane);
-                        else lag_chunk<T, FUSE, false>(acc, WA, WB, Rpos, Rneg, Lc, hnx, ek0, nP, lane);
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < T; ++u) WA[u] = (hnx + (long long)u * nP)[lane];
-                    }
-                    hnx += (long long)T * nP;
-                    ek0 += (long long)T * nP;
-                    if (Lc - 2 * T + 1 < M.nLagRows) {
-                        if (chunk_has_e(cb + 1)) lag_chunk<T, FUSE, true>(acc, WB, WA, Rpos, Rneg, Lc - T, hnx, ek0, nP, lane);
-                        else lag_chunk<T, FUSE, false>(acc, WB, WA, Rpos, Rneg, Lc - T, hnx, ek0, nP, lane);
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < T; ++u) WB[u] = (hnx + (long long)u * nP)[lane];
-                    }
-                    cb += 2;
+                for (; nch >= 2; nch -= 2) {
+                    lag_chunk<T, FUSE>(acc, WA, WB, r, lds.Rpos, Lc, hnx, lane);
+                    lag_chunk<T, FUSE>(acc, WB, WA, r, lds.Rpos, Lc - T, hnx + T * MCMC_WAVE, lane);
+                    hnx += 2 * T * MCMC_WAVE;
                     Lc -= 2 * T;
                 }
-                const double* ekb = ebase + (long long)b * T * nP;
-                if (cb < b) {
-                    const double* hnx = hbase + (long long)(cb + 2) * T * nP;
-                    const double* ek0 = ebase + (long long)cb * T * nP;
-                    if (chunk_has_e(cb)) lag_chunk<T, FUSE, true>(acc, WA, WB, Rpos, Rneg, Lc, hnx, ek0, nP, lane);
-                    else lag_chunk<T, FUSE, false>(acc, WA, WB, Rpos, Rneg, Lc, hnx, ek0, nP, lane);
-                    if (chunk_has_e(b)) lag_tail<T, FUSE, true>(acc, WB, Rpos, Rneg, ekb, nP, lane);
-                    else lag_tail<T, FUSE, false>(acc, WB, Rpos, Rneg, ekb, nP, lane);
-                } else {
-                    if (chunk_has_e(b)) lag_tail<T, FUSE, true>(acc, WA, Rpos, Rneg, ekb, nP, lane);
-                    else lag_tail<T, FUSE, false>(acc, WA, Rpos, Rneg, ekb, nP, lane);
+                if (nch) {
+                    lag_chunk<T, FUSE>(acc, WA, WB, r, lds.Rpos, Lc, hnx, lane);
+#pragma unroll
+                    for (int q = 0; q < T; ++q) WA[q] = WB[q];
+                }
+                /* what phase B needs from memory, requested before the tail's 7*T*(T-1)/2
+                 * multiply-adds: the behaviour values of the block's days */
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int bi = min(max(j0 + t - md, 0), M.nB - 1);
+                    beh[t] = B.x_u[bi * MCMC_WAVE + lane];
+                }
+                lag_tail<T, FUSE, false>(acc, WA, lds.Rpos, lds.Rneg, nullptr, lane);
+            } else {
+                /* some earlier day of this wave carries a capacity correction: per chunk,
+                 * take the variant with the e-terms where its source days need it */
+                const double* ek0 = ebase + c0 * T * MCMC_WAVE;
+                int c = c0;
+#pragma unroll 1
+                for (; nch > 0; --nch, ++c) {
+                    const int klo = a0 + c * T, khi = klo + 2 * T - 2;
+                    if (klo <= keHi && khi >= keLo) lag_chunk_e<T, FUSE>(acc, WA, WB, r, lds.Rpos, lds.Rneg, Lc, hnx, ek0, lane);
+                    else lag_chunk<T, FUSE>(acc, WA, WB, r, lds.Rpos, Lc, hnx, lane);
+#pragma unroll
+                    for (int q = 0; q < T; ++q) { const double tmp = WA[q]; WA[q] = WB[q]; WB[q] = tmp; }
+                    hnx += T * MCMC_WAVE;
+                    ek0 += T * MCMC_WAVE;
+                    Lc -= T;
+                }
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int bi = min(max(j0 + t - md, 0), M.nB - 1);
+                    beh[t] = B.x_u[bi * MCMC_WAVE + lane];
+                }
+                lag_tail<T, FUSE, true>(acc, WA, lds.Rpos, lds.Rneg, ebase + b * T * MCMC_WAVE, lane);
+            }
+            /* the window registers are free now: request the first window of the NEXT block
+             * before the sequential phase B, unless this block is about to write into it
+             * (only the first block of a shift does: its days are ws .. ws+T-1 <= a0+2T-1) */
+            if (b > 0) {
+#pragma unroll
+                for (int q = 0; q < T; ++q) {
+                    WA[q] = hbase[q * MCMC_WAVE + lane];
+                    WB[q] = hbase[(q + T) * MCMC_WAVE + lane];
                 }
             }
 
@@ -396,43 +471,44 @@ __device__ double eval_model(const DevModel& M, const LdsView& lds, const WaveBa
                 /* today's new infections into today and the rest of the block (covid.h:403-410) */
 #pragma unroll
                 for (int tt = t; tt < T; ++tt) {
-                    const int d = tt - t;
-                    acc[A_MI][tt] = madd<FUSE>(ncur, Rp[d * 8 + 0], acc[A_MI][tt]);
-                    acc[A_HI][tt] = madd<FUSE>(ncur, Rp[d * 8 + 1], acc[A_HI][tt]);
-                    acc[A_INC][tt] = madd<FUSE>(ncur, Rp[d * 8 + 2], acc[A_INC][tt]);
-                    acc[A_MILD][tt] = madd<FUSE>(ncur, Rp[d * 8 + 3], acc[A_MILD][tt]);
-                    acc[A_SER][tt] = madd<FUSE>(ncur, Rp[d * 8 + 4], acc[A_SER][tt]);
-                    acc[A_REC][tt] = madd<FUSE>(ncur, Rp[d * 8 + 5], acc[A_REC][tt]);
-                    acc[A_DEAD][tt] = madd<FUSE>(ncur, Rp[d * 8 + 6], acc[A_DEAD][tt]);
+                    const double8_t r0 = lds_row8(lds.Rpos, tt - t);
+                    acc[A_MI][tt] = madd<FUSE>(ncur, r0[0], acc[A_MI][tt]);
+                    acc[A_HI][tt] = madd<FUSE>(ncur, r0[1], acc[A_HI][tt]);
+                    acc[A_INC][tt] = madd<FUSE>(ncur, r0[2], acc[A_INC][tt]);
+                    acc[A_MILD][tt] = madd<FUSE>(ncur, r0[3], acc[A_MILD][tt]);
+                    acc[A_SER][tt] = madd<FUSE>(ncur, r0[4], acc[A_SER][tt]);
+                    acc[A_REC][tt] = madd<FUSE>(ncur, r0[5], acc[A_REC][tt]);
+                    acc[A_DEAD][tt] = madd<FUSE>(ncur, r0[6], acc[A_DEAD][tt]);
                 }
                 /* hospital capacity (covid.h:413-429) */
                 const double overCapacity = acc[A_SER][t] * M.probICU - lds.capacity[i];
                 const double extraDeaths = M.probLethal * overCapacity;
                 const bool hasE = (i >= s) && (extraDeaths > 0);
                 const double e = hasE ? extraDeaths : 0.0;
-                (B.he_u + (long long)(i + MCMC_HOFF(T)) * nP)[lane] = e;
+                B.he_u[(i + MCMC_HOFF(T)) * MCMC_WAVE + lane] = e;
                 if (__builtin_amdgcn_readfirstlane(__any(hasE) ? 1 : 0)) {
                     keLo = min(keLo, i);
                     keHi = max(keHi, i);
                     const double ne = -e;
 #pragma unroll
                     for (int tt = t; tt < T; ++tt) {
-                        const int d = tt - t;
+                        const double4_t rn = lds_row4(lds.Rneg, tt - t);
                         acc[A_DEAD][tt] = acc[A_DEAD][tt] + e;
-                        acc[A_SER][tt] = madd<FUSE>(ne, Rn[d * 4 + 0], acc[A_SER][tt]);
-                        acc[A_REC][tt] = madd<FUSE>(ne, Rn[d * 4 + 1], acc[A_REC][tt]);
-                        acc[A_DEAD][tt] = madd<FUSE>(ne, Rn[d * 4 + 2], acc[A_DEAD][tt]);
+                        acc[A_SER][tt] = madd<FUSE>(ne, rn[0], acc[A_SER][tt]);
+                        acc[A_REC][tt] = madd<FUSE>(ne, rn[1], acc[A_REC][tt]);
+                        acc[A_DEAD][tt] = madd<FUSE>(ne, rn[2], acc[A_DEAD][tt]);
                     }
                 }
                 /* piecewise-constant factor and behaviour (covid.h:432-454) */
-                const int sg = lds.seg[i];                          /* wave-uniform */
-                double pcf = 1.0;
-                if (sg >= 0) pcf = (xdisc_u + (long long)sg * nP)[lane];
-                double smoothbehavior = 1.0;
-                if (i >= md) {
-                    const int bi = min(i - md, M.nB - 1);
-                    smoothbehavior = pcf * (B.x_u + (long long)bi * nP)[lane];
+                const int sg = __builtin_amdgcn_readfirstlane(lds.seg[i]);
+                if (sg != segCur) {                                 /* a few times per pass */
+                    segCur = sg;
+                    pcfCur = 1.0;
+                    if (sg >= 0) pcfCur = xdisc_u[sg * MCMC_WAVE + lane];
                 }
+                const double pcf = pcfCur;
+                double smoothbehavior = 1.0;
+                if (i >= md) smoothbehavior = pcf * beh[t];
                 const double totalBehavior = pcf * smoothbehavior;
                 /* tomorrow's new infections (covid.h:461-462); asymptomatic == mild buffer */
                 const double nSus = M.pop - acc[A_INC][t] - acc[A_MILD][t] - acc[A_MILD][t] -
@@ -440,35 +516,48 @@ __device__ double eval_model(const DevModel& M, const LdsView& lds, const WaveBa
                 double nnext = totalBehavior * nSus / M.pop *
                                (lp.betaMild * acc[A_MI][t] + lp.betaHigh * acc[A_HI][t]);
                 if (i < s) nnext = (i + 1 == s) ? 1.0 : 0.0;       /* not started yet */
-                (B.hn_u + (long long)(i + 1 + MCMC_HOFF(T)) * nP)[lane] = nnext;
+                B.hn_u[(i + 1 + MCMC_HOFF(T)) * MCMC_WAVE + lane] = nnext;
 
-                /* log-likelihood term of data day i-md (covid.h:467-492) */
-                if (i >= md && i - md < M.nData) {
-                    const int di = i - md;
-                    double* dslot = B.d1s_u + (long long)di * nP;
-                    double dead;
-                    if (shift == 1) {
-                        dead = w * acc[A_DEAD][t];                 /* multset, covid.h:475 */
-                        dslot[lane] = dead;
-                    } else {
-                        dead = dslot[lane] + w * acc[A_DEAD][t];   /* multadd, covid.h:484 */
-                    }
-                    const double delta = dead - lds.deaths[di];
-                    loglike += w * (-0.5 * delta * delta / lds.sigma2[di]);
-                }
+                /* this pass's weighted deaths of data day i-md (covid.h:475,484); the
+                 * likelihood terms are summed after the day loop */
+                if (i >= md && i - md < M.nData)
+                    ds_u[(i - md) * MCMC_WAVE + lane] = w * acc[A_DEAD][t];
                 if constexpr (DERIVE) {
                     if (i < M.size) {
                         const double vals[8] = {acc[A_MI][t], acc[A_HI][t], acc[A_INC][t], acc[A_MILD][t],
                                                 acc[A_MILD][t], acc[A_SER][t], acc[A_REC][t], acc[A_DEAD][t]};
 #pragma unroll
                         for (int c = 0; c < 8; ++c) {
-                            double* o = B.curves_u + ((long long)c * M.size + i) * nP;
+                            double* o = B.curves_u + ((size_t)c * M.size + i) * MCMC_WAVE;
                             if (shift == 1) o[lane] = w * vals[c]; else o[lane] += w * vals[c];
                         }
-                        (B.curves_u + ((long long)8 * M.size + i) * nP)[lane] = (i >= s) ? totalBehavior : 1.0;
+                        B.curves_u[((size_t)8 * M.size + i) * MCMC_WAVE + lane] = (i >= s) ? totalBehavior : 1.0;
                     }
                 }
                 ncur = nnext;
+            }
+            if (b == 0) {
+#pragma unroll
+                for (int q = 0; q < T; ++q) {
+                    WA[q] = hbase[q * MCMC_WAVE + lane];
+                    WB[q] = hbase[(q + T) * MCMC_WAVE + lane];
+                }
+            }
+        }
+
+        /* log-likelihood of this pass (covid.h:488-492), data days in order: the output
+         * coord `dead` is the first pass's weighted deaths (multset, covid.h:475), plus this
+         * pass's in the second (multadd, covid.h:484).  A streaming loop over two per-lane
+         * rows and the LDS-resident observations. */
+        {
+            const double* d1_u = B.d1s_u;
+            const double* d0_u = B.d1s_u + M.nData * MCMC_WAVE;
+#pragma unroll 4
+            for (int di = 0; di < M.nData; ++di) {
+                double dead = d1_u[di * MCMC_WAVE + lane];
+                if (shift == 0) dead = dead + d0_u[di * MCMC_WAVE + lane];
+                const double delta = dead - lds.deaths[di];
+                loglike += w * (-0.5 * delta * delta / lds.sigma2[di]);
             }
         }
     }
@@ -477,14 +566,13 @@ __device__ double eval_model(const DevModel& M, const LdsView& lds, const WaveBa
 
 /* SmoothnessPrior::eval (mcmc.h:197-214) on behavior = x[0..nB) */
 __device__ inline double eval_prior(const DevModel& M, const double* x_u, unsigned lane) {
-    const long long nP = M.nP;
     const int n = M.nB;
     const double dx = M.smoothL / (double)n;
     double loglike = 0;
-    double fm = x_u[lane], f0 = (x_u + nP)[lane];
+    double fm = x_u[lane], f0 = x_u[MCMC_WAVE + lane];
 #pragma unroll 4
     for (int i = 1; i + 1 < n; ++i) {
-        const double fp = (x_u + (long long)(i + 1) * nP)[lane];
+        const double fp = x_u[(i + 1) * MCMC_WAVE + lane];
         const double dd = fp + fm - 2 * f0;
         loglike -= dd * dd / dx / dx / dx;
         fm = f0;
@@ -495,10 +583,9 @@ __device__ inline double eval_prior(const DevModel& M, const double* x_u, unsign
 }
 
 __device__ inline void load_lane_scalars(const DevModel& M, const double* x_u, unsigned lane, LaneScalars& lp) {
-    const long long nP = M.nP;
-    lp.betaMild = (x_u + (long long)(M.nB + M.nDisc) * nP)[lane];
-    lp.betaHigh = (x_u + (long long)(M.nB + M.nDisc + 1) * nP)[lane];
-    lp.delay = (x_u + (long long)(M.nB + M.nDisc + 2) * nP)[lane];
+    lp.betaMild = x_u[(M.nB + M.nDisc) * MCMC_WAVE + lane];
+    lp.betaHigh = x_u[(M.nB + M.nDisc + 1) * MCMC_WAVE + lane];
+    lp.delay = x_u[(M.nB + M.nDisc + 2) * MCMC_WAVE + lane];
 }
 
 /*
@@ -508,12 +595,11 @@ __device__ inline void load_lane_scalars(const DevModel& M, const double* x_u, u
  */
 __device__ inline bool propose(const DevModel& M, Pcg32& rnd, const double* xc_u, double* xp_u,
                                unsigned lane, double stepsize, LaneScalars& lp) {
-    const long long nP = M.nP;
     load_lane_scalars(M, xc_u, lane, lp);
     double disc[MCMC_MAXDISC];
 #pragma unroll
     for (int m = 0; m < MCMC_MAXDISC; ++m)
-        disc[m] = (m < M.nDisc) ? (xc_u + (long long)(M.nB + m) * nP)[lane] : 1.0;
+        disc[m] = (m < M.nDisc) ? xc_u[(M.nB + m) * MCMC_WAVE + lane] : 1.0;
     const double sfmin = fmin(stepsize, 1.0);
 
     const bool big1 = rnd.next_float() < 0.6f;                      /* covid.h:503-507 */
@@ -576,42 +662,45 @@ __device__ inline bool propose(const DevModel& M, Pcg32& rnd, const double* xc_u
     if (__any(doB)) {
 #pragma unroll 2
         for (int i = 0; i < M.nB; ++i) {
-            double v = (xc_u + (long long)i * nP)[lane];
+            double v = xc_u[i * MCMC_WAVE + lane];
             if (doB) {
                 v += A * (mcmc_cos(omega * (double)i) - 1);
                 v = bound_reflect(v, 0.0, 2.0);
             }
-            (xp_u + (long long)i * nP)[lane] = v;
+            xp_u[i * MCMC_WAVE + lane] = v;
         }
     } else {
 #pragma unroll 4
-        for (int i = 0; i < M.nB; ++i) (xp_u + (long long)i * nP)[lane] = (xc_u + (long long)i * nP)[lane];
+        for (int i = 0; i < M.nB; ++i) xp_u[i * MCMC_WAVE + lane] = xc_u[i * MCMC_WAVE + lane];
     }
 #pragma unroll
     for (int m = 0; m < MCMC_MAXDISC; ++m)
-        if (m < M.nDisc) (xp_u + (long long)(M.nB + m) * nP)[lane] = disc[m];
-    (xp_u + (long long)(M.nB + M.nDisc) * nP)[lane] = lp.betaMild;
-    (xp_u + (long long)(M.nB + M.nDisc + 1) * nP)[lane] = lp.betaHigh;
-    (xp_u + (long long)(M.nB + M.nDisc + 2) * nP)[lane] = lp.delay;
+        if (m < M.nDisc) xp_u[(M.nB + m) * MCMC_WAVE + lane] = disc[m];
+    xp_u[(M.nB + M.nDisc) * MCMC_WAVE + lane] = lp.betaMild;
+    xp_u[(M.nB + M.nDisc + 1) * MCMC_WAVE + lane] = lp.betaHigh;
+    xp_u[(M.nB + M.nDisc + 2) * MCMC_WAVE + lane] = lp.delay;
     return doB;
 }
 
 /* ------------------------------------------------------------ chain state ---- */
+/* all arrays tile-major (see "Addressing convention"); nTiles = ceil(nChains/64) */
 struct ChainState {
-    double* params;               /* [dim][nP] current state of every chain             */
-    double* prop;                 /* [dim][nP] proposal scratch                         */
-    double* ll;                   /* [2][nP]: model, prior                              */
-    double* stepsize;             /* [nP]                                               */
-    uint64_t* rng;                /* [2][nP]: state, inc                                */
-    int* nAccept;                 /* [nP]                                               */
-    unsigned long long* pairs;    /* [nP]                                               */
-    double* hn; double* he;       /* [histRows][nP]                                     */
-    double* d1s;                  /* [nData][nP]                                        */
-    double* mean;                 /* [dim][nP] or null                                  */
-    double* recLL;                /* [nSavedCap][nP]                                    */
-    double* recSamples;           /* [nSavedCap][dim][nP] or null                       */
+    double* params;               /* [nTiles][dim][64] current state of every chain      */
+    double* prop;                 /* [nTiles][dim][64] proposal scratch                  */
+    double* ll;                   /* [nTiles][2][64]: model, prior                       */
+    double* stepsize;             /* [nTiles][64]                                        */
+    uint64_t* rng;                /* [nTiles][2][64]: state, inc                         */
+    int* nAccept;                 /* [nTiles][64]                                        */
+    unsigned long long* pairs;    /* [nTiles][64]                                        */
+    double* hn; double* he;       /* [nTiles][histRows][64]                              */
+    double* d1s;                  /* [nTiles][2*nData][64]                               */
+    double* mean;                 /* [nTiles][dim][64] or null                           */
+    double* recLL;                /* [nSavedCap][nTiles][64]                             */
+    double* recSamples;           /* [nSavedCap][nTiles][dim][64] or null                */
     long long nChains;
+    int nTiles;
     int dim;
+    int histRows;
 };
 
 enum { SF_RANDOM = 1, SF_RESET_ACC = 2, SF_ADJUST_END = 4, SF_RECORD = 8, SF_MEAN = 16 };
@@ -621,7 +710,19 @@ __device__ __forceinline__ double rate2corr(double x) {
     return (1 + 0.726484 * x * x * x * x) / (0.82051 + 0.0427315 / (x + 0.0001));
 }
 
-#define MCMC_KERNEL_ATTRS __launch_bounds__(MCMC_WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+#define MCMC_BLOCK (MCMC_WAVE * MCMC_WAVES_PER_BLOCK)
+#define MCMC_KERNEL_ATTRS __launch_bounds__(MCMC_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2)))
+
+__device__ __forceinline__ WaveBases wave_bases(const DevModel& M, const ChainState& S, int tile,
+                                                const double* x_u) {
+    WaveBases B;
+    B.x_u = x_u;
+    B.hn_u = S.hn + (size_t)tile * S.histRows * MCMC_WAVE;
+    B.he_u = S.he + (size_t)tile * S.histRows * MCMC_WAVE;
+    B.d1s_u = S.d1s + (size_t)tile * 2 * M.nData * MCMC_WAVE;
+    B.curves_u = nullptr;
+    return B;
+}
 
 /*
  * n_steps Metropolis-Hastings steps for every chain: Target::step (mcmc.h:750-783) with
@@ -632,27 +733,28 @@ __device__ __forceinline__ double rate2corr(double x) {
 template <int T, bool FUSE>
 __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n_steps,
                                                  const double* __restrict__ betas,
-                                                 const int* __restrict__ flags, int slot0, int simPad) {
-    extern __shared__ double lds_raw[];
-    const LdsView lds = stage_lds(M, lds_raw, simPad);
-    const unsigned lane = threadIdx.x;
-    const long long wave0 = (long long)blockIdx.x * MCMC_WAVE;      /* first chain of this wave */
-    const long long nP = M.nP;
-    const long long bufStride = (long long)S.dim * nP;
-    const double* xc_u = S.params + wave0;
-    double* xcw_u = S.params + wave0;
-    double* xp_u = S.prop + wave0;
+                                                 const int* __restrict__ flags, int slot0) {
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    const LdsView lds = stage_lds(M, lds_raw, false, T);
+    const unsigned lane = threadIdx.x & (MCMC_WAVE - 1);
+    const int tile = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * MCMC_WAVES_PER_BLOCK + threadIdx.x / MCMC_WAVE));
+    if (tile >= S.nTiles) return;
+    const size_t tileVec = (size_t)S.dim * MCMC_WAVE;
+    const double* xc_u = S.params + (size_t)tile * tileVec;
+    double* xcw_u = S.params + (size_t)tile * tileVec;
+    double* xp_u = S.prop + (size_t)tile * tileVec;
+    uint64_t* rng_u = S.rng + (size_t)tile * 2 * MCMC_WAVE;
+    double* ll_u = S.ll + (size_t)tile * 2 * MCMC_WAVE;
+    const size_t flat = (size_t)tile * MCMC_WAVE + lane;
 
     Pcg32 rnd;
-    rnd.state = (S.rng + wave0)[lane];
-    rnd.inc = (S.rng + nP + wave0)[lane];
-    double llModel = (S.ll + wave0)[lane], llPrior = (S.ll + nP + wave0)[lane];
-    double stepsize = (S.stepsize + wave0)[lane];
-    int nAccept = (S.nAccept + wave0)[lane];
-    unsigned long long pairs = (S.pairs + wave0)[lane];
-    WaveBases B;
-    B.x_u = xp_u; B.hn_u = S.hn + wave0; B.he_u = S.he + wave0; B.d1s_u = S.d1s + wave0;
-    B.curves_u = nullptr;
+    rnd.state = rng_u[lane];
+    rnd.inc = rng_u[MCMC_WAVE + lane];
+    double llModel = ll_u[lane], llPrior = ll_u[MCMC_WAVE + lane];
+    double stepsize = S.stepsize[flat];
+    int nAccept = S.nAccept[flat];
+    unsigned long long pairs = S.pairs[flat];
+    const WaveBases B = wave_bases(M, S, tile, xp_u);
     int slot = slot0;
 
 #pragma unroll 1
@@ -665,16 +767,16 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
             double l = 0;
             l += llModel;
             if (M.hasPrior) l += llPrior;
-            (S.recLL + (long long)slot * nP + wave0)[lane] = 0.0 + beta * l; /* log(weight()==1) = 0 */
+            S.recLL[((size_t)slot * S.nTiles + tile) * MCMC_WAVE + lane] = 0.0 + beta * l; /* log(weight()==1) = 0 */
             if (S.recSamples) {
-                double* dst = S.recSamples + (long long)slot * bufStride + wave0;
-                for (int k = 0; k < S.dim; ++k) (dst + (long long)k * nP)[lane] = (xc_u + (long long)k * nP)[lane];
+                double* dst = S.recSamples + ((size_t)slot * S.nTiles + tile) * tileVec;
+                for (int k = 0; k < S.dim; ++k) dst[k * MCMC_WAVE + lane] = xc_u[k * MCMC_WAVE + lane];
             }
             ++slot;
         }
         if ((fl & SF_MEAN) && S.mean) {                             /* mcmc.h:1064-1065 */
-            double* mu = S.mean + wave0;
-            for (int k = 0; k < S.dim; ++k) (mu + (long long)k * nP)[lane] += (xc_u + (long long)k * nP)[lane];
+            double* mu = S.mean + (size_t)tile * tileVec;
+            for (int k = 0; k < S.dim; ++k) mu[k * MCMC_WAVE + lane] += xc_u[k * MCMC_WAVE + lane];
         }
 
         if (fl & SF_RANDOM) {                                       /* mcmc.h:494-500 */
@@ -706,8 +808,8 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
         const bool accept = u < 1.0 * mcmc_exp(delta);              /* mcmc.h:776 */
         if (__any(accept)) {                                        /* State::accept, mcmc.h:653-661 */
             for (int k = 0; k < S.dim; ++k) {
-                const double v = (xp_u + (long long)k * nP)[lane];
-                if (accept) (xcw_u + (long long)k * nP)[lane] = v;
+                const double v = xp_u[k * MCMC_WAVE + lane];
+                if (accept) xcw_u[k * MCMC_WAVE + lane] = v;
             }
         }
         if (accept) {
@@ -721,66 +823,67 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
         }
     }
 
-    (S.rng + wave0)[lane] = rnd.state;
-    (S.ll + wave0)[lane] = llModel;
-    (S.ll + nP + wave0)[lane] = llPrior;
-    (S.stepsize + wave0)[lane] = stepsize;
-    (S.nAccept + wave0)[lane] = nAccept;
-    (S.pairs + wave0)[lane] = pairs;
+    rng_u[lane] = rnd.state;
+    ll_u[lane] = llModel;
+    ll_u[MCMC_WAVE + lane] = llPrior;
+    S.stepsize[flat] = stepsize;
+    S.nAccept[flat] = nAccept;
+    S.pairs[flat] = pairs;
 }
 
-/* State::eval (mcmc.h:385-393) of parameter vectors laid out [dim][nP]: llOut[2][nP] */
+/* State::eval (mcmc.h:385-393) of parameter vectors laid out [nTiles][dim][64]:
+ * llOut[nTiles][2][64] */
 template <int T, bool FUSE>
-__global__ MCMC_KERNEL_ATTRS void eval_kernel(DevModel M, ChainState S, const double* x, double* llOut,
-                                              int simPad) {
-    extern __shared__ double lds_raw[];
-    const LdsView lds = stage_lds(M, lds_raw, simPad);
-    const unsigned lane = threadIdx.x;
-    const long long wave0 = (long long)blockIdx.x * MCMC_WAVE;
-    const long long nP = M.nP;
-    WaveBases B;
-    B.x_u = x + wave0; B.hn_u = S.hn + wave0; B.he_u = S.he + wave0; B.d1s_u = S.d1s + wave0;
-    B.curves_u = nullptr;
+__global__ MCMC_KERNEL_ATTRS void eval_kernel(DevModel M, ChainState S, const double* x, double* llOut) {
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    const LdsView lds = stage_lds(M, lds_raw, false, T);
+    const unsigned lane = threadIdx.x & (MCMC_WAVE - 1);
+    const int tile = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * MCMC_WAVES_PER_BLOCK + threadIdx.x / MCMC_WAVE));
+    if (tile >= S.nTiles) return;
+    const WaveBases B = wave_bases(M, S, tile, x + (size_t)tile * S.dim * MCMC_WAVE);
     LaneScalars lp;
     load_lane_scalars(M, B.x_u, lane, lp);
     unsigned long long pairs = 0;
     const double llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, pairs);
     const double llp = M.hasPrior ? eval_prior(M, B.x_u, lane) : 0.0;
-    (llOut + wave0)[lane] = llm;
-    (llOut + nP + wave0)[lane] = llp;
+    llOut[((size_t)tile * 2) * MCMC_WAVE + lane] = llm;
+    llOut[((size_t)tile * 2 + 1) * MCMC_WAVE + lane] = llp;
 }
 
-/* derived output coords (covid.h:467-485) of parameter vectors [dim][nP]:
- * curves[(c*size+i)*nP + chain] */
+/* derived output coords (covid.h:467-485) of parameter vectors [nTiles][dim][64]:
+ * curves[nTiles][9*size][64] */
 template <int T, bool FUSE>
-__global__ MCMC_KERNEL_ATTRS void derive_kernel(DevModel M, ChainState S, const double* x, double* curves,
-                                                int simPad) {
-    extern __shared__ double lds_raw[];
-    const LdsView lds = stage_lds(M, lds_raw, simPad);
-    const unsigned lane = threadIdx.x;
-    const long long wave0 = (long long)blockIdx.x * MCMC_WAVE;
-    WaveBases B;
-    B.x_u = x + wave0; B.hn_u = S.hn + wave0; B.he_u = S.he + wave0; B.d1s_u = S.d1s + wave0;
-    B.curves_u = curves + wave0;
+__global__ MCMC_KERNEL_ATTRS void derive_kernel(DevModel M, ChainState S, const double* x, double* curves) {
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    const LdsView lds = stage_lds(M, lds_raw, true, T);
+    const unsigned lane = threadIdx.x & (MCMC_WAVE - 1);
+    const int tile = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * MCMC_WAVES_PER_BLOCK + threadIdx.x / MCMC_WAVE));
+    if (tile >= S.nTiles) return;
+    WaveBases B = wave_bases(M, S, tile, x + (size_t)tile * S.dim * MCMC_WAVE);
+    B.curves_u = curves + (size_t)tile * 9 * M.size * MCMC_WAVE;
     LaneScalars lp;
     load_lane_scalars(M, B.x_u, lane, lp);
     unsigned long long pairs = 0;
     (void)eval_model<T, FUSE, true>(M, lds, B, lp, lane, pairs);
 }
 
-/* [n][dim] chain-major (host layout) <-> [dim][nP] SoA */
-__global__ void transpose_in_kernel(const double* __restrict__ src, double* __restrict__ dst,
-                                    long long n, int dim, long long nP) {
+/* [n][rows] chain-major (host layout) <-> [nTiles][rows][64] tiles; pad lanes of the last
+ * tile copy the last chain */
+template <typename Tp>
+__global__ void tile_in_kernel(const Tp* __restrict__ src, Tp* __restrict__ dst, long long n, int rows,
+                               long long nP) {
     const long long chain = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (chain >= nP) return;
-    const long long srcChain = chain < n ? chain : n - 1;           /* pad lanes copy the last chain */
-    for (int k = 0; k < dim; ++k) dst[(long long)k * nP + chain] = src[srcChain * dim + k];
+    const long long srcChain = chain < n ? chain : n - 1;
+    Tp* d = dst + (chain / MCMC_WAVE) * rows * MCMC_WAVE + chain % MCMC_WAVE;
+    for (int k = 0; k < rows; ++k) d[(long long)k * MCMC_WAVE] = src[srcChain * rows + k];
 }
-__global__ void transpose_out_kernel(const double* __restrict__ src, double* __restrict__ dst,
-                                     long long n, int dim, long long nP) {
+template <typename Tp>
+__global__ void tile_out_kernel(const Tp* __restrict__ src, Tp* __restrict__ dst, long long n, int rows) {
     const long long chain = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (chain >= n) return;
-    for (int k = 0; k < dim; ++k) dst[chain * dim + k] = src[(long long)k * nP + chain];
+    const Tp* s = src + (chain / MCMC_WAVE) * rows * MCMC_WAVE + chain % MCMC_WAVE;
+    for (int k = 0; k < rows; ++k) dst[chain * rows + k] = s[(long long)k * MCMC_WAVE];
 }
 __global__ void scale_kernel(double* __restrict__ a, long long count, double f) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -791,13 +894,15 @@ __global__ void scale_kernel(double* __restrict__ a, long long count, double f) 
  * atomic add per wave and quantity.  out[0]=sum nAccept, out[2]=sum ll, out[3]=sum ll^2,
  * out[4+2k]=sum x_k, out[5+2k]=sum x_k^2 */
 __global__ __launch_bounds__(MCMC_WAVE) void diagnostics_kernel(DevModel M, ChainState S, double* out) {
-    const long long chain = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long nP = M.nP;
+    const int tile = blockIdx.x;
+    const unsigned lane = threadIdx.x;
+    const long long chain = (long long)tile * MCMC_WAVE + lane;
     const bool live = chain < S.nChains;
-    const double* xb = S.params + chain;
+    const double* xb = S.params + (size_t)tile * S.dim * MCMC_WAVE;
+    const double* ll_u = S.ll + (size_t)tile * 2 * MCMC_WAVE;
     const double acc = live ? (double)S.nAccept[chain] : 0.0;
     double l = 0;
-    if (live) { l += S.ll[chain]; if (M.hasPrior) l += S.ll[nP + chain]; }
+    if (live) { l += ll_u[lane]; if (M.hasPrior) l += ll_u[MCMC_WAVE + lane]; }
     const double sAcc = wave_sum_f64(acc), sL = wave_sum_f64(l), sL2 = wave_sum_f64(l * l);
     if (threadIdx.x == 0) {
         atomicAdd(&out[0], sAcc);
@@ -805,7 +910,7 @@ __global__ __launch_bounds__(MCMC_WAVE) void diagnostics_kernel(DevModel M, Chai
         atomicAdd(&out[3], sL2);
     }
     for (int k = 0; k < S.dim; ++k) {
-        const double x = live ? xb[(long long)k * nP] : 0.0;
+        const double x = live ? xb[k * MCMC_WAVE + lane] : 0.0;
         const double sx = wave_sum_f64(x), sx2 = wave_sum_f64(x * x);
         if (threadIdx.x == 0) {
             atomicAdd(&out[4 + 2 * k], sx);

@@ -11,7 +11,8 @@ import numpy as np
 from . import covid_config as CC
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcmc_hip.so")
+# MCMC_HIP_LIB selects another build of the same library (kernel-variant experiments)
+LIB_PATH = os.environ.get("MCMC_HIP_LIB") or os.path.join(_HERE, "libmcmc_hip.so")
 
 NCURVES = 10
 OUT_CURVES = ["mildlyInfectious", "highlyInfectious", "incubating", "asymptomatic", "mild",
