@@ -60,7 +60,7 @@ def build_workload(device, n_chains, first_chain_id, contract, n_data=N_DATA):
     return cfg, R, xs, sampler
 
 
-def cpu_baseline(cfg, R10, xs, contract, seconds=15.0):
+def cpu_baseline(cfg, R10, xs, contract, seconds=20.0):
     """The oracle (a CPU port of the same path, oracle/mcmc_oracle.c) timed on this box's
     host cores on a bounded sample of the same workload.  Reported, not the target."""
     from oracle import oracle as O
@@ -74,7 +74,7 @@ def cpu_baseline(cfg, R10, xs, contract, seconds=15.0):
     n_chains = 4 * threads
     cal = O.run_chains(m, tgt, xs[:n_chains], 1.0, 4, 0, 0, 1000, n_threads=threads)
     per_step = cal["wall"] / 4
-    n_samples = int(max(8, min(4000, seconds / max(per_step, 1e-6))))
+    n_samples = int(max(8, min(40000, seconds / max(per_step, 1e-6))))
     res = O.run_chains(m, tgt, xs[:n_chains], 1.0, n_samples, 0, 0, 1000, n_threads=threads)
     return {"value": res["steps"] / res["wall"], "unit": "MH steps/s", "cores": threads, "kind": "port",
             "sample": f"{n_chains} chains x {n_samples} steps of the same 365-day workload "

@@ -180,6 +180,12 @@ int mcmc_hip_last_timing(mcmc_hip_ctx* ctx, double* adjust_s, double* sampling_s
  * summed over chains: each pair is one multiply-add per compartment (covid.h:384). */
 int mcmc_hip_pair_count(mcmc_hip_ctx* ctx, double* pairs_out, int32_t reset);
 
+/* Profiling aid: shader cycles summed over all waves per phase of the MH step since the last
+ * reset, out[16] in the order propose, eval set-up, lag chunks, lag tail, day loop,
+ * log-likelihood, prior, accept, record, lag chunks with e-terms.  All zeros unless the library was built with
+ * -DMCMC_STAMPS (the stamps cost a few per cent). */
+int mcmc_hip_debug_phase_cycles(mcmc_hip_ctx* ctx, double* out, int32_t reset);
+
 #ifdef __cplusplus
 }
 #endif

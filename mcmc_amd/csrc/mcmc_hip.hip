@@ -793,6 +793,20 @@ int mcmc_hip_last_timing(mcmc_hip_ctx* c, double* adjust_s, double* sampling_s, 
     return 0;
 }
 
+int mcmc_hip_debug_phase_cycles(mcmc_hip_ctx* c, double* out, int32_t reset) {
+    if (int r = check_ctx(c)) return r;
+    if (!out) return fail(MCMC_HIP_EINVAL, "null output buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long h[16];
+    HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_cycles), sizeof(h)));
+    for (int k = 0; k < 16; ++k) out[k] = (double)h[k];
+    if (reset) {
+        memset(h, 0, sizeof(h));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), h, sizeof(h)));
+    }
+    return 0;
+}
+
 int mcmc_hip_pair_count(mcmc_hip_ctx* c, double* pairs_out, int32_t reset) {
     if (int r = need_chains(c, pairs_out)) return r;
     std::vector<unsigned long long> h(c->nP);

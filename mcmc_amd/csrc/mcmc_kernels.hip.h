@@ -2,8 +2,10 @@
  * mcmc_kernels.hip.h -- CDNA4 (gfx950) device code of the Metropolis-Hastings hot path.
  *
  * One chain per lane; 64 chains per wavefront advance in lockstep.  All chain state
- * lives in HBM as structure-of-arrays [field][chain] so that every per-lane access of a
- * wave is one contiguous 512-byte line.  Citations are file:line under /root/reference.
+ * lives in HBM as tile-major structure-of-arrays [tile of 64 chains][field][lane] so that
+ * every per-lane access of a wave is one contiguous 512-byte line and everything a wave
+ * touches of one array is one contiguous block.  Citations are file:line under
+ * /root/reference.
  *
  * THE MODEL TIME-STEPPER (DiseaseSpread::eval, covid.h:325-496) -- how it is laid out
  * ------------------------------------------------------------------------------------
@@ -22,12 +24,20 @@
  * Days are processed in blocks of T.  A block keeps 7*T accumulators in VGPRs
  * (asymptomaticBuf is projected with traj.mild, covid.h:406, so it equals mildBuf and
  * needs none of its own).  Phase A walks the lags L = j-k from large to small (= k
- * ascending); at each lag ONE history value per lane is loaded (coalesced 8 B/lane)
- * and feeds 7*T multiply-adds whose second operand R_c[L] is wave-uniform and comes
- * in through the scalar cache as an SGPR operand -- no VGPR, no LDS traffic for the
- * table.  Phase B then runs the T days of the block in order (the feedback
- * n_{i+1} = f(buffers[i]) is inherently sequential, covid.h:461-462), pushing each new
- * n_i into the later days of the block from registers.
+ * ascending) in chunks of T lags: per lag ONE history value per lane is loaded
+ * (coalesced 8 B/lane, requested two chunks = 16 lags ahead) and feeds 7*T multiply-adds
+ * whose second operand R_c[L] is wave-uniform: one row of the response table, read from
+ * the workgroup's LDS image as a broadcast one lag ahead of use.  Source days that carry a
+ * hospital-capacity correction form a wave-uniform day range; only the chunks reading
+ * that range take the variant with the extra e-terms.  Phase B then runs the T days of
+ * the block in order (the feedback n_{i+1} = f(buffers[i]) is inherently sequential,
+ * covid.h:461-462), pushing each new n_i into the later days of the block from registers.
+ * The per-day likelihood terms are summed in a streaming pass after the day loop.
+ *
+ * A wave runs alone on its SIMD (64k chains = 1024 waves = one per SIMD of the chip), so
+ * nothing hides a stall for it: every load in the lag loop is software-pipelined, and the
+ * code is shaped so that the compiler keeps the accumulators and both register windows in
+ * place across the loop (no copies, no spills inside it; tools/asm_blocks.py audits that).
  *
  * Only what the log-likelihood can see is simulated in the sampling kernels: days
  * [0, maxDelay+nData).  The nPredictDays tail (covid.h:297) cannot influence `loglike`
@@ -104,6 +114,43 @@ __device__ __forceinline__ double madd(double a, double b, double c) {
     if constexpr (FUSE) return __builtin_fma(a, b, c);
     else return c + a * b;
 }
+
+/* ------------------------------------------------ optional in-kernel phase stamps ---- */
+/* Built with -DMCMC_STAMPS the kernels accumulate, per phase of an MH step, the shader
+ * cycles (s_memtime) every wave spends there into g_phase_cycles; mcmc_hip_debug_phase_cycles
+ * reads them.  Without the macro the hooks compile to nothing. */
+enum { PH_PROPOSE = 0, PH_SETUP, PH_CHUNKS, PH_TAIL, PH_DAYS, PH_LOGLIKE, PH_PRIOR, PH_ACCEPT, PH_RECORD, PH_CHUNKS_E, PH_NCHUNK, PH_NCHUNK_E, PH_COUNT };
+__device__ unsigned long long g_phase_cycles[16];
+#ifdef MCMC_STAMPS
+struct PhaseClock {
+    unsigned long long t[PH_COUNT];
+    unsigned long long last;
+    __device__ __forceinline__ void start() {
+#pragma unroll
+        for (int k = 0; k < PH_COUNT; ++k) t[k] = 0;
+        last = __builtin_amdgcn_s_memtime();
+    }
+    __device__ __forceinline__ void stamp(int k) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        t[k] += now - last;
+        last = now;
+    }
+    __device__ __forceinline__ void count(int k, int n) { t[k] += (unsigned long long)n; }
+    __device__ __forceinline__ void flush(unsigned lane) {
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < PH_COUNT; ++k) atomicAdd(&g_phase_cycles[k], t[k]);
+        }
+    }
+};
+#else
+struct PhaseClock {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void stamp(int) {}
+    __device__ __forceinline__ void count(int, int) {}
+    __device__ __forceinline__ void flush(unsigned) {}
+};
+#endif
 
 /* mcmc.h:49-53; std::round is half-away-from-zero */
 __device__ __forceinline__ double bound_reflect(double val, double lower, double upper) {
@@ -241,20 +288,23 @@ __device__ __forceinline__ void lag_chunk(double (&acc)[A_NPOS][T], double (&W)[
 
 /* The same chunk when some source day of it carries a hospital-capacity correction e_k
  * (covid.h:416-429): after the eight projections of day k come add(e_k) and the three
- * negative projections, in that order.  Rarer path, kept small: the e-history is re-read
- * where it is needed (L1-resident) instead of holding a second register window. */
+ * negative projections, in that order.  The e-history has a register window of its own
+ * (EW/EN, refilled like W/N) and the row of the three *FromSerious curves is read one step
+ * ahead like r. */
 template <int T, bool FUSE>
 __device__ __forceinline__ void lag_chunk_e(double (&acc)[A_NPOS][T], double (&W)[T], const double (&N)[T],
-                                            double8_t& r, const double* Rpos, const double* Rneg, int Lc,
-                                            const double* hn_next_u, const double* he_k0_u, unsigned lane) {
+                                            double (&EW)[T], const double (&EN)[T], double8_t& r, double4_t& rn,
+                                            const double* Rpos, const double* Rneg, int Lc,
+                                            const double* hn_next_u, const double* he_next_u, unsigned lane) {
 #pragma unroll
     for (int u = 0; u < T; ++u) {
         const double8_t rnext = lds_row8(Rpos, Lc - u - 1);
-        const double4_t rn = lds_row4(Rneg, Lc - u);
+        const double4_t rnnext = lds_row4(Rneg, Lc - u - 1);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int q = t + u;
             const double nk = (q < T) ? W[q < T ? q : 0] : N[q < T ? 0 : q - T];
+            const double ek = (q < T) ? EW[q < T ? q : 0] : EN[q < T ? 0 : q - T];
             acc[A_MI][t] = madd<FUSE>(nk, r[0], acc[A_MI][t]);
             acc[A_HI][t] = madd<FUSE>(nk, r[1], acc[A_HI][t]);
             acc[A_INC][t] = madd<FUSE>(nk, r[2], acc[A_INC][t]);
@@ -262,7 +312,6 @@ __device__ __forceinline__ void lag_chunk_e(double (&acc)[A_NPOS][T], double (&W
             acc[A_SER][t] = madd<FUSE>(nk, r[4], acc[A_SER][t]);
             acc[A_REC][t] = madd<FUSE>(nk, r[5], acc[A_REC][t]);
             acc[A_DEAD][t] = madd<FUSE>(nk, r[6], acc[A_DEAD][t]);
-            const double ek = he_k0_u[q * MCMC_WAVE + lane];
             const double nek = -ek;
             acc[A_DEAD][t] = acc[A_DEAD][t] + ek;                       /* add(), covid.h:418 */
             acc[A_SER][t] = madd<FUSE>(nek, rn[0], acc[A_SER][t]);      /* covid.h:426 */
@@ -270,7 +319,9 @@ __device__ __forceinline__ void lag_chunk_e(double (&acc)[A_NPOS][T], double (&W
             acc[A_DEAD][t] = madd<FUSE>(nek, rn[2], acc[A_DEAD][t]);    /* covid.h:428 */
         }
         W[u] = hn_next_u[u * MCMC_WAVE + lane];
+        EW[u] = he_next_u[u * MCMC_WAVE + lane];
         r = rnext;
+        rn = rnnext;
     }
 }
 
@@ -317,7 +368,8 @@ __device__ __forceinline__ void lag_tail(double (&acc)[A_NPOS][T], const double 
  */
 template <int T, bool FUSE, bool DERIVE>
 __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& lds, const WaveBases& B,
-                                             const LaneScalars& lp, unsigned lane, unsigned long long& pairs) {
+                                             const LaneScalars& lp, unsigned lane, unsigned long long& pairs,
+                                             PhaseClock& pc) {
     const int md = M.md;
     const int horizon = DERIVE ? M.size : M.simDays;
     const double* xdisc_u = B.x_u + M.nB * MCMC_WAVE;
@@ -377,6 +429,7 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
         }
         int segCur = -2;
         double pcfCur = 1.0;
+        pc.stamp(PH_SETUP);
         double* ds_u = B.d1s_u + (shift == 1 ? 0 : M.nData * MCMC_WAVE);
 
 #pragma unroll 1
@@ -407,52 +460,83 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
             }
             double8_t r = lds_row8(lds.Rpos, Lc);
             const double* hnx = hbase + (c0 + 2) * T * MCMC_WAVE;   /* refill source of chunk c0 */
-            int nch = b - c0;
-            if (!anyE) {
-                /* the common case: two chunks per iteration, the window halves swap roles */
-#pragma unroll 1
-                for (; nch >= 2; nch -= 2) {
-                    lag_chunk<T, FUSE>(acc, WA, WB, r, lds.Rpos, Lc, hnx, lane);
-                    lag_chunk<T, FUSE>(acc, WB, WA, r, lds.Rpos, Lc - T, hnx + T * MCMC_WAVE, lane);
-                    hnx += 2 * T * MCMC_WAVE;
-                    Lc -= 2 * T;
-                }
-                if (nch) {
-                    lag_chunk<T, FUSE>(acc, WA, WB, r, lds.Rpos, Lc, hnx, lane);
-#pragma unroll
-                    for (int q = 0; q < T; ++q) WA[q] = WB[q];
-                }
-                /* what phase B needs from memory, requested before the tail's 7*T*(T-1)/2
-                 * multiply-adds: the behaviour values of the block's days */
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const int bi = min(max(j0 + t - md, 0), M.nB - 1);
-                    beh[t] = B.x_u[bi * MCMC_WAVE + lane];
-                }
-                lag_tail<T, FUSE, false>(acc, WA, lds.Rpos, lds.Rneg, nullptr, lane);
-            } else {
-                /* some earlier day of this wave carries a capacity correction: per chunk,
-                 * take the variant with the e-terms where its source days need it */
-                const double* ek0 = ebase + c0 * T * MCMC_WAVE;
-                int c = c0;
-#pragma unroll 1
-                for (; nch > 0; --nch, ++c) {
-                    const int klo = a0 + c * T, khi = klo + 2 * T - 2;
-                    if (klo <= keHi && khi >= keLo) lag_chunk_e<T, FUSE>(acc, WA, WB, r, lds.Rpos, lds.Rneg, Lc, hnx, ek0, lane);
-                    else lag_chunk<T, FUSE>(acc, WA, WB, r, lds.Rpos, Lc, hnx, lane);
-#pragma unroll
-                    for (int q = 0; q < T; ++q) { const double tmp = WA[q]; WA[q] = WB[q]; WB[q] = tmp; }
-                    hnx += T * MCMC_WAVE;
-                    ek0 += T * MCMC_WAVE;
-                    Lc -= T;
-                }
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const int bi = min(max(j0 + t - md, 0), M.nB - 1);
-                    beh[t] = B.x_u[bi * MCMC_WAVE + lane];
-                }
-                lag_tail<T, FUSE, true>(acc, WA, lds.Rpos, lds.Rneg, ebase + b * T * MCMC_WAVE, lane);
+            /* Source days that carry a capacity correction form the wave-uniform range
+             * [keLo, keHi]; chunk c reads source days [a0+c*T, a0+c*T+2T-2].  So the chunks
+             * split into three runs: plain, with e-terms, plain.  Each run is a loop of its own
+             * (two chunks per iteration, the window halves swapping roles). */
+            int cLo = b, cHi = b - 1;
+            if (anyE) {
+                const int num = keLo - a0 - 2 * T + 2;
+                cLo = num <= 0 ? 0 : (num + T - 1) / T;
+                cHi = (keHi - a0) / T;
+                cLo = max(cLo, c0);
+                cHi = min(cHi, b - 1);
+                if (cHi < cLo) { cLo = b; cHi = b - 1; }
             }
+            const double* ek0 = ebase + cLo * T * MCMC_WAVE;
+#pragma unroll 1
+            for (int seg = 0; seg < 3; ++seg) {
+                int nch = (seg == 0) ? cLo - c0 : (seg == 1) ? cHi - cLo + 1 : b - 1 - cHi;
+                pc.count(seg == 1 ? PH_NCHUNK_E : PH_NCHUNK, nch);
+                if (seg != 1) {
+#pragma unroll 1
+                    for (; nch >= 2; nch -= 2) {
+                        lag_chunk<T, FUSE>(acc, WA, WB, r, lds.Rpos, Lc, hnx, lane);
+                        lag_chunk<T, FUSE>(acc, WB, WA, r, lds.Rpos, Lc - T, hnx + T * MCMC_WAVE, lane);
+                        hnx += 2 * T * MCMC_WAVE;
+                        Lc -= 2 * T;
+                    }
+                    if (nch > 0) {
+                        lag_chunk<T, FUSE>(acc, WA, WB, r, lds.Rpos, Lc, hnx, lane);
+#pragma unroll
+                        for (int q = 0; q < T; ++q) { const double tmp = WA[q]; WA[q] = WB[q]; WB[q] = tmp; }
+                        hnx += T * MCMC_WAVE;
+                        Lc -= T;
+                    }
+                } else if (nch > 0) {
+                    /* e-window of the run's first chunk (one exposed round trip per block),
+                     * refilled two chunks ahead from then on */
+                    double EA[T], EB[T];
+#pragma unroll
+                    for (int q = 0; q < T; ++q) {
+                        EA[q] = ek0[q * MCMC_WAVE + lane];
+                        EB[q] = ek0[(q + T) * MCMC_WAVE + lane];
+                    }
+                    const double* ekx = ek0 + 2 * T * MCMC_WAVE;
+                    double4_t rn = lds_row4(lds.Rneg, Lc);
+#pragma unroll 1
+                    for (; nch >= 2; nch -= 2) {
+                        lag_chunk_e<T, FUSE>(acc, WA, WB, EA, EB, r, rn, lds.Rpos, lds.Rneg, Lc, hnx, ekx, lane);
+                        lag_chunk_e<T, FUSE>(acc, WB, WA, EB, EA, r, rn, lds.Rpos, lds.Rneg, Lc - T,
+                                             hnx + T * MCMC_WAVE, ekx + T * MCMC_WAVE, lane);
+                        hnx += 2 * T * MCMC_WAVE;
+                        ekx += 2 * T * MCMC_WAVE;
+                        Lc -= 2 * T;
+                    }
+                    if (nch > 0) {
+                        lag_chunk_e<T, FUSE>(acc, WA, WB, EA, EB, r, rn, lds.Rpos, lds.Rneg, Lc, hnx, ekx, lane);
+#pragma unroll
+                        for (int q = 0; q < T; ++q) { const double tmp = WA[q]; WA[q] = WB[q]; WB[q] = tmp; }
+                        hnx += T * MCMC_WAVE;
+                        Lc -= T;
+                    }
+                }
+                pc.stamp(seg == 1 ? PH_CHUNKS_E : PH_CHUNKS);
+            }
+            /* what phase B needs from memory, requested before the tail's 7*T*(T-1)/2
+             * multiply-adds: the behaviour values of the block's days */
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int bi = min(max(j0 + t - md, 0), M.nB - 1);
+                beh[t] = B.x_u[bi * MCMC_WAVE + lane];
+            }
+            pc.stamp(PH_CHUNKS);
+            /* the tail reads source days [j0-T+1, j0-1] */
+            if (anyE && j0 - T + 1 <= keHi && j0 - 1 >= keLo)
+                lag_tail<T, FUSE, true>(acc, WA, lds.Rpos, lds.Rneg, ebase + b * T * MCMC_WAVE, lane);
+            else
+                lag_tail<T, FUSE, false>(acc, WA, lds.Rpos, lds.Rneg, nullptr, lane);
+            pc.stamp(PH_TAIL);
             /* the window registers are free now: request the first window of the NEXT block
              * before the sequential phase B, unless this block is about to write into it
              * (only the first block of a shift does: its days are ws .. ws+T-1 <= a0+2T-1) */
@@ -543,6 +627,7 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                     WB[q] = hbase[(q + T) * MCMC_WAVE + lane];
                 }
             }
+            pc.stamp(PH_DAYS);
         }
 
         /* log-likelihood of this pass (covid.h:488-492), data days in order: the output
@@ -560,6 +645,7 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                 loglike += w * (-0.5 * delta * delta / lds.sigma2[di]);
             }
         }
+        pc.stamp(PH_LOGLIKE);
     }
     return loglike;
 }
@@ -711,7 +797,10 @@ __device__ __forceinline__ double rate2corr(double x) {
 }
 
 #define MCMC_BLOCK (MCMC_WAVE * MCMC_WAVES_PER_BLOCK)
-#define MCMC_KERNEL_ATTRS __launch_bounds__(MCMC_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2)))
+#ifndef MCMC_WPE_MIN
+#define MCMC_WPE_MIN 1
+#endif
+#define MCMC_KERNEL_ATTRS __launch_bounds__(MCMC_BLOCK) __attribute__((amdgpu_waves_per_eu(MCMC_WPE_MIN, 2)))
 
 __device__ __forceinline__ WaveBases wave_bases(const DevModel& M, const ChainState& S, int tile,
                                                 const double* x_u) {
@@ -756,6 +845,8 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
     unsigned long long pairs = S.pairs[flat];
     const WaveBases B = wave_bases(M, S, tile, xp_u);
     int slot = slot0;
+    PhaseClock pc;
+    pc.start();
 
 #pragma unroll 1
     for (int g = 0; g < n_steps; ++g) {
@@ -788,9 +879,11 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
             } while (head != 0);    /* SmoothnessPrior has no steppable coords: redraw */
         }
 
+        pc.stamp(PH_RECORD);
         LaneScalars lp;
         const bool behChanged = propose(M, rnd, xc_u, xp_u, lane, stepsize, lp);
-        const double llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, pairs);
+        pc.stamp(PH_PROPOSE);
+        const double llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, pairs, pc);
         double llp = 0.0;
         double delta = 0;                                           /* mcmc.h:604-606 */
         delta += -llModel + llm;
@@ -802,6 +895,7 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
             }
             delta += -llPrior + llp;
         }
+        pc.stamp(PH_PRIOR);
         delta += 0.0;                                               /* log(wNew)-log(wOld), mcmc.h:765 */
         delta *= beta;                                              /* mcmc.h:766 */
         const double u = (double)rnd.next_float();
@@ -821,7 +915,9 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
             const double acceptRate = (double)nAccept / 20;
             stepsize *= rate2corr(acceptRate);
         }
+        pc.stamp(PH_ACCEPT);
     }
+    pc.flush(lane);
 
     rng_u[lane] = rnd.state;
     ll_u[lane] = llModel;
@@ -844,7 +940,9 @@ __global__ MCMC_KERNEL_ATTRS void eval_kernel(DevModel M, ChainState S, const do
     LaneScalars lp;
     load_lane_scalars(M, B.x_u, lane, lp);
     unsigned long long pairs = 0;
-    const double llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, pairs);
+    PhaseClock pc;
+    pc.start();
+    const double llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, pairs, pc);
     const double llp = M.hasPrior ? eval_prior(M, B.x_u, lane) : 0.0;
     llOut[((size_t)tile * 2) * MCMC_WAVE + lane] = llm;
     llOut[((size_t)tile * 2 + 1) * MCMC_WAVE + lane] = llp;
@@ -864,7 +962,9 @@ __global__ MCMC_KERNEL_ATTRS void derive_kernel(DevModel M, ChainState S, const 
     LaneScalars lp;
     load_lane_scalars(M, B.x_u, lane, lp);
     unsigned long long pairs = 0;
-    (void)eval_model<T, FUSE, true>(M, lds, B, lp, lane, pairs);
+    PhaseClock pc;
+    pc.start();
+    (void)eval_model<T, FUSE, true>(M, lds, B, lp, lane, pairs, pc);
 }
 
 /* [n][rows] chain-major (host layout) <-> [nTiles][rows][64] tiles; pad lanes of the last

@@ -28,6 +28,7 @@ SYMBOLS = [
     "mcmc_hip_get_accept_counts", "mcmc_hip_get_rng_state", "mcmc_hip_get_loglikes",
     "mcmc_hip_get_samples", "mcmc_hip_get_sample_all", "mcmc_hip_get_mean", "mcmc_hip_eval",
     "mcmc_hip_derive", "mcmc_hip_diagnostics", "mcmc_hip_last_timing", "mcmc_hip_pair_count",
+    "mcmc_hip_debug_phase_cycles",
 ]
 
 
@@ -95,6 +96,7 @@ def lib():
     L.mcmc_hip_derive.argtypes = [vp, C.c_int64, dp, dp]
     L.mcmc_hip_last_timing.argtypes = [vp, dp, dp, dp, C.POINTER(C.c_int64)]
     L.mcmc_hip_pair_count.argtypes = [vp, dp, C.c_int32]
+    L.mcmc_hip_debug_phase_cycles.argtypes = [vp, dp, C.c_int32]
     _lib = L
     return L
 
@@ -250,6 +252,13 @@ class CovidSampler:
         n = C.c_int64()
         _check(lib().mcmc_hip_last_timing(self._h, C.byref(a), C.byref(s), C.byref(k), C.byref(n)))
         return dict(adjust_s=a.value, sampling_s=s.value, step_kernel_s=k.value, launches=n.value)
+
+    PHASES = ["propose", "setup", "chunks", "tail", "days", "loglike", "prior", "accept", "record", "chunks_e", "n_chunks", "n_chunks_e"]
+
+    def phase_cycles(self, reset=False):
+        out = np.zeros(16)
+        _check(lib().mcmc_hip_debug_phase_cycles(self._h, _dp(out), int(reset)))
+        return dict(zip(self.PHASES, out[:len(self.PHASES)]))
 
     def pair_count(self, reset=False):
         v = C.c_double()

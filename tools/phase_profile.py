@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of the MH step (needs a library built with -DMCMC_STAMPS):
+   MCMC_HIP_LIB=.../libmcmc_hip_stamps.so python tools/phase_profile.py [chains] [steps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+cfg, R, xs, s = bench.build_workload(0, n, 1, 1)
+s.step(16, 1.0, True)
+s.phase_cycles(reset=True)
+s.step(steps, 1.0, True)
+ph = s.phase_cycles()
+counts = {k: ph.pop(k) for k in ("n_chunks", "n_chunks_e")}
+tot = sum(ph.values())
+waves = (n + 63) // 64
+for k, v in ph.items():
+    print(f"{k:8s} {v / waves / steps:12.0f} cycles/wave/step  {100 * v / max(tot, 1):5.1f} %")
+print(f"total    {tot / waves / steps:12.0f} cycles/wave/step")
+for k, v in counts.items():
+    print(f"{k:10s} {v / waves / steps:10.1f} per wave per step")
