@@ -1,0 +1,952 @@
+/*
+ * mcmc_host.hpp -- C++17 host side of the MI355X Metropolis-Hastings hot path.
+ *
+ * Mirrors, for the covid path, the interface of AndreasFinke/mcmc that a user program or
+ * the pybind11 module touches: SubspaceState / SmoothnessPrior / DiseaseData /
+ * DiseaseParams / DiseaseSpread / State / Target / TempTarget / CoolingTarget /
+ * MetropolisChain / ChainManager (mcmc.h:62-228, 241-700, 705-841, 984-1312, 1314-1655;
+ * covid.h:16-93, 284-321, 629-646).  Same names, argument order and error behaviour
+ * (messages on std::cout and an early return, as the reference does).  What differs is
+ * where the work runs: nothing here evaluates the model on the CPU.  State::eval,
+ * MetropolisChain::run and ChainManager::run_all* hand the parameters to libmcmc_hip.so
+ * through the C ABI of include/mcmc_hip.h, and ALL chains of a manager advance in one
+ * launch sequence on the GPU (the reference runs one TBB task per chain,
+ * mcmc.h:1494-1508, 1534-1548).  There is no CPU fallback: without the library or a GPU
+ * the calls report the C ABI's error.
+ *
+ * Only the State composition of the covid notebooks is supported:
+ *     State = [ DiseaseSpread ]  or  [ DiseaseSpread, SmoothnessPrior("behavior", Ls, L) ].
+ * Everything is header-only and uses nothing but the C ABI, so a C++ program can use it
+ * without Python; mcmc_amd/pymod/mcmc_module.cpp wraps it for Python.
+ */
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <optional>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mcmc_hip.h"
+
+namespace mcmc_amd {
+
+using Float = double;                      /* mcmc.h:43 */
+
+/* mcmc.h:49-53 (host copy: force_bounds runs where the reference runs it) */
+inline void bound(Float& val, Float lower, Float upper) {
+    val = 0.5 * (val - lower) / (upper - lower);
+    val = 2 * std::abs(val - std::round(val));
+    val = lower + val * (upper - lower);
+}
+
+/* wjakob/pcg32 as the reference seeds and draws it (mcmc.h:1319,1625) */
+struct pcg32 {
+    uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
+    pcg32() = default;
+    pcg32(uint64_t initstate, uint64_t initseq) {
+        state = 0; inc = (initseq << 1u) | 1u; nextUInt(); state += initstate; nextUInt();
+    }
+    uint32_t nextUInt() {
+        uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        uint32_t x = (uint32_t)(((old >> 18u) ^ old) >> 27u), r = (uint32_t)(old >> 59u);
+        return (x >> r) | (x << ((~r + 1u) & 31));
+    }
+    double nextDouble() {
+        union { uint64_t u; double d; } x;
+        x.u = ((uint64_t)nextUInt() << 20) | 0x3ff0000000000000ULL;
+        return x.d - 1.0;
+    }
+};
+
+struct HipError : std::runtime_error {
+    int code;
+    HipError(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+inline void hip_check(int rc, const char* where) {
+    if (rc != 0) throw HipError(rc, std::string(where) + ": " + mcmc_hip_last_error());
+}
+
+/* ------------------------------------------------------------------ SubspaceState ---- */
+/* mcmc.h:62-183: named ragged coords, loglike, stepsizeCorrectionFac, fixed set.  The
+ * virtuals that evaluate or step a likelihood on the CPU are not part of this mirror. */
+class SubspaceState {
+public:
+    Float loglike = 0;
+    Float stepsizeCorrectionFac = 1;
+    bool derivedOnShared = false;
+    std::set<std::pair<size_t, size_t>> fixed = {};
+    int dim = 0;
+
+    SubspaceState(std::vector<std::string>&& coordNames, bool derivedParamsDependOnSharedParams = false,
+                  size_t nDerived = 0)
+        : derivedOnShared(derivedParamsDependOnSharedParams), nDerived(nDerived) {
+        for (size_t i = 0; i < coordNames.size(); ++i) names[coordNames[i]] = i;
+    }
+    virtual ~SubspaceState() {}
+    virtual std::shared_ptr<SubspaceState> copy() const = 0;
+    virtual void force_bounds() {}
+
+    void setCoords(std::vector<std::vector<Float>> init) {           /* mcmc.h:81-88 */
+        coords = init;
+        dim = 0;
+        for (size_t i = 0; i + nDerived < init.size(); ++i) dim += (int)init[i].size();
+    }
+    auto& getCoords() { return coords; }
+    const auto& getCoords() const { return coords; }
+    std::optional<std::vector<Float>> getCoords(const std::string& name) const {
+        auto it = names.find(name);
+        if (it != names.end()) return coords[it->second];
+        return {};
+    }
+    std::vector<Float>& getCoordsAt(const std::string& name) { return coords[names.at(name)]; }
+    std::map<std::string, std::vector<Float>> getAll() const {
+        std::map<std::string, std::vector<Float>> ret;
+        for (auto& [name, idx] : names) ret[name] = coords[idx];
+        return ret;
+    }
+    bool isDerived(const std::string& name) const {
+        auto it = names.find(name);
+        return it != names.end() && it->second >= names.size() - nDerived;
+    }
+    std::map<std::string, size_t> get_names() const { return names; }
+    size_t numDerived() const { return nDerived; }
+
+protected:
+    std::vector<std::vector<Float>> coords = {};
+    std::map<std::string, size_t> names = {};
+    size_t nDerived = 0;
+};
+
+/* mcmc.h:185-228 */
+class SmoothnessPrior : public SubspaceState {
+public:
+    SmoothnessPrior(const std::string& functionName, Float smoothnessScale, Float scale)
+        : SubspaceState({}), L(scale), Lsmooth(smoothnessScale), functionName(functionName) {}
+    Float L, Lsmooth;
+    std::string functionName;
+    std::shared_ptr<SubspaceState> copy() const override { return std::make_shared<SmoothnessPrior>(*this); }
+};
+
+/* covid.h:16-57; the arrays are [2][nData] (deaths, sigma) and [3][nDisc] (day, value,
+ * flag: >= 0 sampled, < 0 fixed), row-major */
+class DiseaseData {
+public:
+    DiseaseData(const Float* deathsAndSigma, size_t nData, const Float* daysValsFlags, size_t nDisc) {
+        deathsPerDay.assign(deathsAndSigma, deathsAndSigma + nData);
+        deathsSigma.assign(deathsAndSigma + nData, deathsAndSigma + 2 * nData);
+        discontinuousDays.resize(nDisc);
+        discontinuousVals.resize(nDisc);
+        discontinuousValsFixed.resize(nDisc);
+        for (size_t i = 0; i < nDisc; ++i) {
+            discontinuousDays[i] = (int)std::round(daysValsFlags[i]);
+            discontinuousVals[i] = daysValsFlags[nDisc + i];
+            discontinuousValsFixed[i] = !(daysValsFlags[2 * nDisc + i] >= 0);
+        }
+    }
+    std::vector<Float> deathsPerDay, deathsSigma;
+    std::vector<int> discontinuousDays;
+    std::vector<Float> discontinuousVals;
+    std::vector<bool> discontinuousValsFixed;
+    Float initialBetaMild = 2;
+    Float initialBetaHigh = 7;
+    Float initialDelay = 14;
+    int fixBehaviorInAdvance = 14;
+};
+
+/* covid.h:59-93 */
+class DiseaseParams {
+public:
+    Float timeIncub = 4, timeIncubSigma = 2, probAsymp = 0.1, probSerious = 0.08, probLethal = 0.004,
+          probLethalDailyWhenSeriousUntreated = 0.2, probICUIfSerious = 0.3, timeMildDuration = 10,
+          timeMildDurationSigma = 5, timeMildToSerious = 8, timeMildToSeriousSigma = 3, timeSeriousToRec = 10,
+          timeSeriousToRecSigma = 5, timeSeriousToDeath = 9, timeSeriousToDeathSigma = 5;
+    mcmc_disease_params c_struct() const {
+        return mcmc_disease_params{timeIncub, timeIncubSigma, probAsymp, probSerious, probLethal,
+                                   probLethalDailyWhenSeriousUntreated, probICUIfSerious, timeMildDuration,
+                                   timeMildDurationSigma, timeMildToSerious, timeMildToSeriousSigma,
+                                   timeSeriousToRec, timeSeriousToRecSigma, timeSeriousToDeath,
+                                   timeSeriousToDeathSigma};
+    }
+};
+
+/* covid.h:284-321, 629-646.  The constructor runs the AvgDiseaseTrajectory precompute
+ * (covid.h:100-203, host, as in the reference) and keeps the 10 x 500 response table the
+ * device kernels read; the 8.8 MB trajectory grid itself is not kept, so copies are cheap
+ * (the reference copies it on every proposal, covid.h:290,501). */
+class DiseaseSpread : public SubspaceState {
+public:
+    const DiseaseData& data;
+    const DiseaseParams& params;
+    int nPredictDays, maxDelayDaysTilData;
+    int popSize;
+    double cap0, capIncrRate;
+    std::shared_ptr<const std::vector<double>> responseTable;      /* [10][500] */
+
+    static constexpr uint64_t kTrajectories = 10000000;             /* covid.h:207 */
+
+    DiseaseSpread(const DiseaseData& data, const DiseaseParams& params, int popSize, double cap0,
+                  double capIncrRate, int maxDelayDaysTilData, size_t nPredictDays,
+                  uint64_t nTrajectories = kTrajectories)
+        : SubspaceState({"behavior", "discontinuousVals", "betaMild", "betaHigh", "delay", "mildlyInfectious",
+                         "highlyInfectious", "incubating", "asymptomatic", "mild", "serious", "recovered", "dead",
+                         "capacity", "totalBehavior"}, false, 10),
+          data(data), params(params), nPredictDays((int)nPredictDays), maxDelayDaysTilData(maxDelayDaysTilData),
+          popSize(popSize), cap0(cap0), capIncrRate(capIncrRate) {
+        const size_t nData = data.deathsPerDay.size();
+        const size_t nDaysTotal = maxDelayDaysTilData + nPredictDays + nData;          /* covid.h:297 */
+        if (nData <= (size_t)data.fixBehaviorInAdvance)
+            throw std::invalid_argument("DiseaseSpread: fixBehaviorInAdvance must be smaller than the number of data days");
+        std::vector<std::vector<Float>> init = {
+            std::vector<Float>(nData - data.fixBehaviorInAdvance, Float(1)), data.discontinuousVals,
+            {data.initialBetaMild}, {data.initialBetaHigh}, {data.initialDelay}};
+        for (int k = 0; k < 9; ++k) init.push_back(std::vector<Float>(nDaysTotal, Float(0)));
+        init.push_back(std::vector<Float>(nDaysTotal, Float(1)));
+        setCoords(init);
+        for (size_t i = 0; i < nDaysTotal; ++i)
+            getCoordsAt("capacity")[i] = cap0 + std::max(capIncrRate * ((double)i - maxDelayDaysTilData), Float(0.0));
+        for (size_t i = 0; i < data.discontinuousValsFixed.size(); ++i)
+            if (data.discontinuousValsFixed[i]) fixed.insert(std::make_pair(size_t(1), i));
+        auto tab = std::make_shared<std::vector<double>>((size_t)MCMC_HIP_NCURVES * MCMC_HIP_TRAJ_NDAYS);
+        const mcmc_disease_params p = params.c_struct();
+        hip_check(mcmc_host_make_response_tables(&p, nTrajectories, MCMC_HIP_TRAJ_NDAYS, tab->data()),
+                  "AvgDiseaseTrajectory");
+        responseTable = tab;
+    }
+
+    void force_bounds() override {                                    /* covid.h:629-646 */
+        bound(getCoordsAt("delay")[0], Float(5), Float(maxDelayDaysTilData));
+        Float lastVal = 1;
+        auto& dv = getCoordsAt("discontinuousVals");
+        for (size_t i = 0; i < dv.size(); ++i) {
+            if (data.discontinuousValsFixed[i]) continue;
+            bound(dv[i], Float(0), lastVal);
+            lastVal = dv[i];
+        }
+        for (auto& b : getCoordsAt("behavior")) bound(b, Float(0), Float(2));
+        bound(getCoordsAt("betaMild")[0], Float(0), Float(100));
+        bound(getCoordsAt("betaHigh")[0], Float(0), Float(100));
+    }
+    std::shared_ptr<SubspaceState> copy() const override { return std::make_shared<DiseaseSpread>(*this); }
+
+    size_t nDaysTotal() const { return maxDelayDaysTilData + nPredictDays + data.deathsPerDay.size(); }
+    size_t nBehavior() const { return data.deathsPerDay.size() - data.fixBehaviorInAdvance; }
+    size_t nSampled() const { return nBehavior() + data.discontinuousVals.size() + 3; }
+
+    /* the sampled coordinates in the C ABI's order (= the coords order, covid.h:294) */
+    std::vector<Float> pack() const {
+        std::vector<Float> x;
+        for (int k = 0; k < 5; ++k) x.insert(x.end(), coords[k].begin(), coords[k].end());
+        return x;
+    }
+    void unpack(const Float* x) {
+        for (int k = 0; k < 5; ++k)
+            for (auto& v : coords[k]) v = *x++;
+    }
+    /* derived output coords from mcmc_hip_derive's [9][size] block (covid.h:467-485) */
+    void set_derived(const Float* curves) {
+        static const char* order[9] = {"mildlyInfectious", "highlyInfectious", "incubating", "asymptomatic", "mild",
+                                       "serious", "recovered", "dead", "totalBehavior"};
+        const size_t n = nDaysTotal();
+        for (int c = 0; c < 9; ++c) getCoordsAt(order[c]).assign(curves + c * n, curves + (c + 1) * n);
+    }
+};
+
+/* ---------------------------------------------------------------- device engine ---- */
+enum class TargetKind { Plain = MCMC_TARGET_PLAIN, Temp = MCMC_TARGET_TEMP, Cooling = MCMC_TARGET_COOLING };
+struct TargetSpec { TargetKind kind = TargetKind::Plain; Float T = 1, slope = 0, Tinit = 1; };
+
+/* RAII owner of one mcmc_hip_ctx for a given model + target */
+class Engine {
+public:
+    Engine(const DiseaseSpread& ds, const SmoothnessPrior* prior, const TargetSpec& t, int device = 0,
+           int contract = default_contract()) {
+        std::vector<int32_t> days(ds.data.discontinuousDays.begin(), ds.data.discontinuousDays.end());
+        std::vector<uint8_t> fixedv(ds.data.discontinuousValsFixed.size());
+        for (size_t i = 0; i < fixedv.size(); ++i) fixedv[i] = ds.data.discontinuousValsFixed[i] ? 1 : 0;
+        mcmc_covid_config cfg{};
+        cfg.n_data = (int32_t)ds.data.deathsPerDay.size();
+        cfg.max_delay = ds.maxDelayDaysTilData;
+        cfg.n_predict = ds.nPredictDays;
+        cfg.n_disc = (int32_t)days.size();
+        cfg.fix_behavior_in_advance = ds.data.fixBehaviorInAdvance;
+        cfg.pop_size = ds.popSize;
+        cfg.prob_icu_if_serious = ds.params.probICUIfSerious;
+        cfg.prob_lethal_daily_untreated = ds.params.probLethalDailyWhenSeriousUntreated;
+        cfg.cap0 = ds.cap0;
+        cfg.cap_incr_rate = ds.capIncrRate;
+        cfg.has_prior = prior ? 1 : 0;
+        cfg.smooth_Ls = prior ? prior->Lsmooth : 0;
+        cfg.smooth_L = prior ? prior->L : 1;
+        cfg.target_kind = (int32_t)t.kind;
+        cfg.target_T = t.T; cfg.target_slope = t.slope; cfg.target_Tinit = t.Tinit;
+        cfg.contract = contract;
+        cfg.disc_days = days.data();
+        cfg.disc_fixed = fixedv.data();
+        hip_check(mcmc_hip_create(&cfg, device, &ctx), "mcmc_hip_create");
+        try {
+            hip_check(mcmc_hip_set_tables(ctx, ds.responseTable->data(), MCMC_HIP_TRAJ_NDAYS), "mcmc_hip_set_tables");
+            hip_check(mcmc_hip_set_data(ctx, ds.data.deathsPerDay.data(), ds.data.deathsSigma.data()), "mcmc_hip_set_data");
+        } catch (...) { mcmc_hip_destroy(ctx); ctx = nullptr; throw; }
+        dim = mcmc_hip_dim(ctx);
+        size = mcmc_hip_size(ctx);
+    }
+    ~Engine() { if (ctx) mcmc_hip_destroy(ctx); }
+    Engine(const Engine&) = delete;
+    Engine& operator=(const Engine&) = delete;
+
+    /* FMA contraction of the projection statement (covid.h:384): what the reference's own
+     * build flags (-march=native, CMakeLists.txt:98) give; MCMC_AMD_CONTRACT=0 selects the
+     * strict two-rounding form */
+    static int default_contract() {
+        const char* e = std::getenv("MCMC_AMD_CONTRACT");
+        return e ? std::atoi(e) : 1;
+    }
+    mcmc_hip_ctx* ctx = nullptr;
+    int dim = 0, size = 0;
+};
+
+/* ------------------------------------------------------------------------- State ---- */
+/* mcmc.h:241-700, restricted to the covid composition */
+class State {
+public:
+    std::vector<std::shared_ptr<SubspaceState>> state;
+    std::vector<std::vector<Float>> initialConditions;
+    Float weight = 1;
+    int dim = 0;
+    bool isInitialized = false;
+    bool isEvaluated = false;
+    int sharedDependencyMaxDepth = 10;
+
+    void add(const std::shared_ptr<SubspaceState>& s) { state.push_back(s); dim += s->dim; }
+
+    DiseaseSpread* disease() const {
+        return state.empty() ? nullptr : dynamic_cast<DiseaseSpread*>(state[0].get());
+    }
+    SmoothnessPrior* prior() const {
+        return state.size() < 2 ? nullptr : dynamic_cast<SmoothnessPrior*>(state[1].get());
+    }
+    bool supported(std::string* why = nullptr) const {
+        auto fail = [&](const char* m) { if (why) *why = m; return false; };
+        if (state.empty() || !disease()) return fail("the first likelihood must be a DiseaseSpread");
+        if (state.size() > 2) return fail("at most [DiseaseSpread, SmoothnessPrior] is supported on the GPU path");
+        if (state.size() == 2 && (!prior() || prior()->functionName != "behavior"))
+            return fail("the second likelihood must be SmoothnessPrior(\"behavior\", ...)");
+        return true;
+    }
+
+    void init() {                                                      /* mcmc.h:401-492 */
+        std::cout << "\nResolving dependencies for state with " << state.size() << " likelihoods \n";
+        std::string why;
+        if (!supported(&why)) {
+            std::cout << "State::init: " << why << ".\n";
+            throw std::string("Missing shared param");                  /* mcmc.h:460 */
+        }
+        if (prior()) std::cout << "Searching for behavior...found in likelihood 0\n";
+        isInitialized = true;
+        eval();
+    }
+
+    /* State::eval (mcmc.h:385-393) on the device: log-likelihoods and the derived curves */
+    void eval() {
+        std::string why;
+        if (!supported(&why)) throw std::runtime_error("State::eval: " + why);
+        DiseaseSpread* ds = disease();
+        Engine eng(*ds, prior(), TargetSpec{});
+        const std::vector<Float> x = ds->pack();
+        Float ll[2] = {0, 0};
+        hip_check(mcmc_hip_eval(eng.ctx, 1, x.data(), ll), "mcmc_hip_eval");
+        std::vector<Float> curves((size_t)9 * eng.size);
+        hip_check(mcmc_hip_derive(eng.ctx, 1, x.data(), curves.data()), "mcmc_hip_derive");
+        ds->loglike = ll[0];
+        ds->set_derived(curves.data());
+        if (prior()) prior()->loglike = ll[1];
+        isEvaluated = true;
+    }
+
+    Float loglikelihood() const {                                      /* mcmc.h:612-618 */
+        Float l = 0;
+        for (auto& s : state) l += s->loglike;
+        return l;
+    }
+    void force_bounds() { for (auto& s : state) s->force_bounds(); }
+    std::map<std::string, std::vector<Float>> get_all() const {
+        std::map<std::string, std::vector<Float>> ret;
+        for (auto& s : state) { auto r = s->getAll(); ret.insert(r.begin(), r.end()); }
+        return ret;
+    }
+    std::optional<std::vector<Float>> getCoords(const std::string& name) const {
+        for (auto& s : state) if (auto c = s->getCoords(name)) return c;
+        return {};
+    }
+    void set_stepsizes(const std::vector<Float>& sz) {
+        for (size_t i = 0; i < state.size() && i < sz.size(); ++i) state[i]->stepsizeCorrectionFac = sz[i];
+    }
+    std::vector<Float> get_stepsizes() const {
+        std::vector<Float> r;
+        for (auto& s : state) r.push_back(s->stepsizeCorrectionFac);
+        return r;
+    }
+    std::shared_ptr<State> deep_copy() const {
+        State ret(*this);
+        for (auto& s : ret.state) s = s->copy();
+        return std::make_shared<State>(ret);
+    }
+    /* DiseaseSpread has no sampleInitialConditions (the base returns {}, mcmc.h:112-114): a
+     * state's initial conditions are its sampled coordinates */
+    std::vector<std::vector<Float>> getInitialConditions() {
+        initialConditions = {disease() ? disease()->pack() : std::vector<Float>{}};
+        for (size_t i = 1; i < state.size(); ++i) initialConditions.push_back({});
+        return initialConditions;
+    }
+    void setInitialConditions(const std::vector<std::vector<Float>>& ics) {
+        if (ics.size() != state.size()) throw std::invalid_argument("setInitialConditions: wrong number of likelihoods");
+        initialConditions = ics;
+        if (disease() && ics[0].size() == disease()->nSampled()) disease()->unpack(ics[0].data());
+        isEvaluated = false;
+        eval();
+    }
+};
+
+/* ------------------------------------------------------------------------ Target ---- */
+/* mcmc.h:705-841 */
+class Target {
+public:
+    virtual ~Target() {}
+    void set_posterior(std::shared_ptr<State> s) {
+        try {
+            if (!s->isInitialized) s->init();
+            if (!s->isEvaluated) {
+                s->eval();
+                std::cout << "Target::set_posterior received unevaluated state and forced evaluation.\n";
+            }
+            state = s;
+            state->weight = weight();
+        } catch (...) {
+            std::cout << "set_posterior failed. Fix Your setup and try again." << std::endl;
+        }
+    }
+    virtual Float weight() const { return 1; }
+    virtual Float beta(Float) { return 1; }
+    virtual TargetSpec spec() const { return TargetSpec{}; }
+    Float logprobability(Float time) { return std::log(weight()) + beta(time) * state->loglikelihood(); }
+    virtual std::shared_ptr<Target> deep_copy() {
+        Target t(*this);
+        if (state) t.state = state->deep_copy();
+        return std::make_shared<Target>(t);
+    }
+    std::shared_ptr<State> state = nullptr;
+};
+class TempTarget : public Target {
+public:
+    TempTarget(Float T = 1) : bet(1 / T), T(T) {}
+    Float bet, T;
+    Float beta(Float) override { return bet; }
+    TargetSpec spec() const override { return TargetSpec{TargetKind::Temp, T, 0, 1}; }
+    std::shared_ptr<Target> deep_copy() override {
+        TempTarget t(*this);
+        if (state) t.state = state->deep_copy();
+        return std::make_shared<TempTarget>(t);
+    }
+};
+class CoolingTarget : public Target {
+public:
+    Float slope, Tinit;
+    CoolingTarget(Float coolingSlope, Float Tinit) : slope(coolingSlope), Tinit(Tinit) {}
+    Float beta(Float time) override { return std::exp(time * slope) / Tinit; }
+    TargetSpec spec() const override { return TargetSpec{TargetKind::Cooling, 1, slope, Tinit}; }
+    std::shared_ptr<Target> deep_copy() override {
+        CoolingTarget t(*this);
+        if (state) t.state = state->deep_copy();
+        return std::make_shared<CoolingTarget>(t);
+    }
+};
+
+/* --------------------------------------------------------------- MetropolisChain ---- */
+/* What one chain recorded (MetropolisChain::loglikes / ics / mean, mcmc.h:1307-1310). */
+struct ChainRecord {
+    std::vector<Float> loglikes;                       /* [nSaved]                            */
+    std::vector<std::vector<Float>> ics;               /* [nSaved][dim] sampled coordinates   */
+    std::vector<Float> mean;                           /* [dim]                               */
+    std::vector<Float> finalParams;                    /* [dim]                               */
+    Float finalLL[2] = {0, 0};
+    Float stepsize = 1;
+    int nAccept = 0;
+};
+
+/* mcmc.h:984-1312.  run() drives the device for this one chain; a chain handed out by
+ * ChainManager::get_chain carries what the manager's batched run recorded for it. */
+class MetropolisChain {
+public:
+    MetropolisChain(std::shared_ptr<Target> target, int chainid) : target(target), id(chainid) {}
+
+    Float weight = 1;
+    bool computeMean = true;
+    bool recordSamples = true;
+    bool writeSamplesToDisk = false;
+    std::shared_ptr<Target> target;
+    int id = 0;
+    ChainRecord rec;
+    bool haveSamples = false;                           /* samples of the reference = ics + late derive */
+
+    void run(int nSamples, int nBurnin, int nAdjust, int thinning) {
+        if (!target || !target->state) { std::cout << "No proposal received...\n"; return; }   /* mcmc.h:752-755,1091 */
+        std::string why;
+        if (!target->state->supported(&why)) { std::cout << "MetropolisChain::run: " << why << ".\n"; return; }
+        if (thinning < 1) { std::cout << "MetropolisChain::run: thinning must be at least 1.\n"; return; }
+        DiseaseSpread* ds = target->state->disease();
+        Engine eng(*ds, target->state->prior(), target->spec());
+        const std::vector<Float> x = ds->pack();
+        const Float ss = ds->stepsizeCorrectionFac;
+        const uint64_t cid = (uint64_t)id;
+        hip_check(mcmc_hip_set_chains(eng.ctx, 1, x.data(), &ss, &cid, 0), "mcmc_hip_set_chains");
+        std::cout << "Starting to adjust and sample.\n";
+        hip_check(mcmc_hip_run(eng.ctx, nSamples, nBurnin, nAdjust, thinning, 1, computeMean ? 1 : 0), "mcmc_hip_run");
+        collect(eng, 0, mcmc_hip_n_saved(nSamples, nBurnin, nAdjust, thinning), true, computeMean, rec);
+        haveSamples = recordSamples || writeSamplesToDisk;
+        apply_final_state(eng);
+        if (writeSamplesToDisk) write_samples(eng);
+        std::cout << "\nThe final acceptance rate was " << (double)rec.nAccept / std::max(nBurnin + nSamples, 1)
+                  << "." << std::endl;                                                        /* mcmc.h:1136 */
+    }
+
+    /* mcmc.h:1141-1199: drop the first nBurnin recorded points and (re)build the samples */
+    void reevaluate(std::shared_ptr<State> evalstate, int nBurnin) {
+        if (!recordSamples && !writeSamplesToDisk) {
+            std::cout << "Re-evaluation of chain " << id << " is not requested to record samples in chain nor write them to disk. Aborting.\n";
+            return;
+        }
+        if (rec.ics.size() == 0) {
+            std::cout << "Re-evaluation of chain " << id << " impossible: No initial conditions have been recorded.\n";
+            return;
+        }
+        if (haveSamples) std::cout << "Re-evaluation of chain " << id << " despite saved samples. Overwriting... \n";
+        if (nBurnin < 0 || (size_t)nBurnin >= rec.ics.size()) {
+            std::cout << "Requested re-evaluation with burnin as big as original run or bigger. Aborting.\n";
+            return;
+        }
+        rec.ics.erase(rec.ics.begin(), rec.ics.begin() + nBurnin);
+        rec.loglikes.erase(rec.loglikes.begin(), rec.loglikes.begin() + nBurnin);
+        if (evalstate && evalstate->supported()) evalState = evalstate;
+        haveSamples = true;
+        if (writeSamplesToDisk) {
+            State* st = evalState ? evalState.get() : target->state.get();
+            Engine eng(*st->disease(), st->prior(), target->spec());
+            write_samples(eng);
+        }
+    }
+
+    /* getters of the pybind surface (mcmc.h:1236-1301), as plain vectors */
+    std::vector<Float> get_mean(const std::string& coordName) {
+        if (!computeMean) std::cout << "Requested mean, but MetropolisChain::computeMean is false\n";
+        const DiseaseSpread* ds = model();
+        size_t off, len;
+        if (!ds || rec.mean.empty() || !sampled_range(*ds, coordName, off, len)) return {};
+        return std::vector<Float>(rec.mean.begin() + off, rec.mean.begin() + off + len);
+    }
+    /* returns row-major [nSamples][len]; len through *lenOut */
+    std::vector<Float> get_samples(const std::string& coordName, size_t* lenOut) {
+        *lenOut = 0;
+        if (!haveSamples || rec.ics.empty()) { std::cout << "Requested samples, but none are present\n"; return {}; }
+        const DiseaseSpread* ds = model();
+        size_t off, len;
+        std::vector<Float> out;
+        if (sampled_range(*ds, coordName, off, len)) {
+            for (auto& x : rec.ics) out.insert(out.end(), x.begin() + off, x.begin() + off + len);
+            *lenOut = len;
+            return out;
+        }
+        static const char* order[9] = {"mildlyInfectious", "highlyInfectious", "incubating", "asymptomatic", "mild",
+                                       "serious", "recovered", "dead", "totalBehavior"};
+        const size_t size = ds->nDaysTotal();
+        if (coordName == "capacity") {
+            auto cap = ds->getCoords("capacity");
+            for (size_t i = 0; i < rec.ics.size(); ++i) out.insert(out.end(), cap->begin(), cap->end());
+            *lenOut = size;
+            return out;
+        }
+        for (int c = 0; c < 9; ++c) {
+            if (coordName != order[c]) continue;
+            /* derived output coords: computed now, for the saved samples only (the
+             * compute_derived_late idea, mcmc.h:100-104) */
+            State* st = evalState ? evalState.get() : target->state.get();
+            Engine eng(*st->disease(), st->prior(), target->spec());
+            const size_t n = rec.ics.size();
+            std::vector<Float> flat;
+            for (auto& x : rec.ics) flat.insert(flat.end(), x.begin(), x.end());
+            std::vector<Float> curves(n * 9 * size);
+            hip_check(mcmc_hip_derive(eng.ctx, (int64_t)n, flat.data(), curves.data()), "mcmc_hip_derive");
+            for (size_t i = 0; i < n; ++i)
+                out.insert(out.end(), curves.begin() + (i * 9 + c) * size, curves.begin() + (i * 9 + c + 1) * size);
+            *lenOut = size;
+            return out;
+        }
+        std::cout << "Requested samples of unknown coordinate " << coordName << "\n";
+        return {};
+    }
+    std::vector<Float> get_weights() {
+        if (!haveSamples || rec.ics.empty()) { std::cout << "Requested weights, but none are present\n"; return {}; }
+        return std::vector<Float>(rec.ics.size(), 1.0);              /* 1/samples[i]->weight, weight() == 1 */
+    }
+    std::vector<Float> get_loglikes() {
+        if (rec.loglikes.empty()) { std::cout << "Requested loglikes, but none are present\n"; return {}; }
+        return rec.loglikes;
+    }
+
+    /* pulls what chain `index` of a finished run recorded out of the engine */
+    static void collect(Engine& eng, int64_t index, int nSaved, bool samples, bool mean, ChainRecord& r) {
+        const int64_t n = mcmc_hip_n_chains(eng.ctx);
+        const int dim = eng.dim;
+        r.loglikes.assign(nSaved, 0);
+        if (nSaved > 0) {
+            std::vector<Float> all((size_t)n * nSaved);
+            hip_check(mcmc_hip_get_loglikes(eng.ctx, all.data()), "mcmc_hip_get_loglikes");
+            std::copy(all.begin() + index * nSaved, all.begin() + (index + 1) * nSaved, r.loglikes.begin());
+        }
+        r.ics.clear();
+        if (samples && nSaved > 0) {
+            std::vector<Float> s((size_t)nSaved * dim);
+            hip_check(mcmc_hip_get_samples(eng.ctx, index, 0, dim, s.data()), "mcmc_hip_get_samples");
+            for (int i = 0; i < nSaved; ++i) r.ics.emplace_back(s.begin() + (size_t)i * dim, s.begin() + (size_t)(i + 1) * dim);
+        }
+        std::vector<Float> buf((size_t)n * dim);
+        if (mean) {
+            hip_check(mcmc_hip_get_mean(eng.ctx, buf.data()), "mcmc_hip_get_mean");
+            r.mean.assign(buf.begin() + index * dim, buf.begin() + (index + 1) * dim);
+        }
+        hip_check(mcmc_hip_get_params(eng.ctx, buf.data()), "mcmc_hip_get_params");
+        r.finalParams.assign(buf.begin() + index * dim, buf.begin() + (index + 1) * dim);
+        std::vector<Float> ll((size_t)n * 2), ss(n);
+        std::vector<int32_t> acc(n);
+        hip_check(mcmc_hip_get_loglike(eng.ctx, ll.data()), "mcmc_hip_get_loglike");
+        hip_check(mcmc_hip_get_stepsizes(eng.ctx, ss.data()), "mcmc_hip_get_stepsizes");
+        hip_check(mcmc_hip_get_accept_counts(eng.ctx, acc.data()), "mcmc_hip_get_accept_counts");
+        r.finalLL[0] = ll[2 * index]; r.finalLL[1] = ll[2 * index + 1];
+        r.stepsize = ss[index];
+        r.nAccept = acc[index];
+    }
+
+    /* the chain's end state becomes the target's state, as after the reference's run() */
+    void apply_final_state(Engine& eng) {
+        DiseaseSpread* ds = target->state->disease();
+        ds->unpack(rec.finalParams.data());
+        ds->loglike = rec.finalLL[0];
+        ds->stepsizeCorrectionFac = rec.stepsize;
+        if (target->state->prior()) target->state->prior()->loglike = rec.finalLL[1];
+        std::vector<Float> curves((size_t)9 * eng.size);
+        hip_check(mcmc_hip_derive(eng.ctx, 1, rec.finalParams.data(), curves.data()), "mcmc_hip_derive");
+        ds->set_derived(curves.data());
+    }
+
+private:
+    std::shared_ptr<State> evalState;
+
+    const DiseaseSpread* model() const {
+        const State* st = evalState ? evalState.get() : (target ? target->state.get() : nullptr);
+        return st ? st->disease() : nullptr;
+    }
+    static bool sampled_range(const DiseaseSpread& ds, const std::string& name, size_t& off, size_t& len) {
+        static const char* order[5] = {"behavior", "discontinuousVals", "betaMild", "betaHigh", "delay"};
+        off = 0;
+        for (int k = 0; k < 5; ++k) {
+            len = ds.getCoords()[k].size();
+            if (name == order[k]) return true;
+            off += len;
+        }
+        return false;
+    }
+    /* text dump in the reference's format (mcmc.h:1013-1019, 1047-1059, 1163-1184) */
+    void write_samples(Engine& eng) {
+        std::stringstream filename;
+        filename << "samples" << id << ".txt";
+        std::ofstream file(filename.str());
+        file << "chainweight = " << weight << "\n\n";
+        State* st = evalState ? evalState.get() : target->state.get();
+        std::shared_ptr<State> work = st->deep_copy();
+        DiseaseSpread* ds = work->disease();
+        const size_t n = rec.ics.size();
+        if (n == 0) return;
+        std::vector<Float> flat;
+        for (auto& x : rec.ics) flat.insert(flat.end(), x.begin(), x.end());
+        std::vector<Float> curves(n * 9 * eng.size), ll(n * 2);
+        hip_check(mcmc_hip_derive(eng.ctx, (int64_t)n, flat.data(), curves.data()), "mcmc_hip_derive");
+        hip_check(mcmc_hip_eval(eng.ctx, (int64_t)n, flat.data(), ll.data()), "mcmc_hip_eval");
+        for (size_t i = 0; i < n; ++i) {
+            ds->unpack(rec.ics[i].data());
+            ds->set_derived(curves.data() + i * 9 * eng.size);
+            file << "weight " << 1.0 << " loglike " << ll[2 * i] + ll[2 * i + 1] << "\n";
+            for (auto& [name, vec] : work->get_all()) {
+                file << name << " ";
+                for (Float x : vec) file << x << " ";
+                file << "\n";
+            }
+            file << "\n";
+        }
+    }
+};
+
+/* ------------------------------------------------------------------ ChainManager ---- */
+/* mcmc.h:1314-1655 for ChainType = MetropolisChain.  The per-chain set-up loop and the
+ * tbb::parallel_for of run_all / run_all_adjust become one mcmc_hip_set_chains +
+ * mcmc_hip_run over all chains; chain i keeps id i+1 (mcmc.h:1487,1527).  The reservoir
+ * constructors evaluate their candidates in one batched mcmc_hip_eval. */
+class ChainManager {
+public:
+    using ICs = std::vector<std::vector<Float>>;
+
+    /* mcmc.h:1317-1347.  DiseaseSpread does not implement sampleInitialConditions, so the
+     * reference's loop pushes the state's current initial conditions nChain times. */
+    ChainManager(std::shared_ptr<Target> target, size_t nChain) : target(target), nChain(nChain) {
+        std::cout << "\nConstructing " << nChain << " random inital states. " << std::endl;
+        target->set_posterior(target->state);
+        const Float prob = target->logprobability(0);
+        if (std::isnan(prob) || std::isinf(prob))
+            throw std::runtime_error("ChainManager: the state's log probability is not finite, no initial state can be drawn");
+        for (size_t i = 0; i < nChain; ++i) {
+            std::cout << "Logprobabilty of state " << i << " is " << prob << "\n";
+            chainICs.push_back(std::make_pair(target->state->getInitialConditions(), 1));
+        }
+        stepsizes = std::vector<Float>(target->state->state.size(), Float(1));
+    }
+    /* mcmc.h:1348-1374 */
+    ChainManager(std::shared_ptr<Target> target, size_t nChainReservoir, size_t nChain) : target(target), nChain(nChain) {
+        pcg32 rnd(0, 0);
+        std::cout << "\nConstructing a discrete distribution of " << nChainReservoir << " random inital states. " << std::endl;
+        if (!target->state->isInitialized) target->state->init();
+        std::vector<ICs> cand(nChainReservoir, target->state->getInitialConditions());
+        build_from_candidates(rnd, cand, std::vector<Float>(nChainReservoir, 0.0));
+        stepsizes = std::vector<Float>(target->state->state.size(), Float(1));
+    }
+    /* mcmc.h:1376-1418: seed the chains from the recorded points of a generator chain,
+     * re-weighted to the new target */
+    ChainManager(std::shared_ptr<MetropolisChain> generator, std::shared_ptr<Target> targetRHS, size_t nChain)
+        : target(targetRHS), nChain(nChain) {
+        pcg32 rnd(0, 0);
+        if (!generator->recordSamples)
+            std::cout << "Re-evaluating chain samples for their likelihood given the current target. This is as many times quicker as the original chain as the thinning.\n";
+        if (generator->rec.ics.empty()) throw std::runtime_error("ChainManager: the generator chain holds no recorded points");
+        if (!target->state->isInitialized) target->state->init();
+        std::vector<ICs> cand;
+        for (auto& x : generator->rec.ics) {
+            ICs ic = {x};
+            for (size_t i = 1; i < target->state->state.size(); ++i) ic.push_back({});
+            cand.push_back(ic);
+        }
+        build_from_candidates(rnd, cand, generator->rec.loglikes);
+        stepsizes = generator->target->state->get_stepsizes();
+    }
+
+    std::vector<Float> stepsizes;
+
+    /* user-supplied initial conditions [nChain][dim], each with weight 1: what a caller
+     * does who diversifies the chains himself (the reference has no way to, see above) */
+    void set_initial_conditions(const std::vector<std::vector<Float>>& x) {
+        chainICs.clear();
+        for (auto& v : x) {
+            ICs ic = {v};
+            for (size_t i = 1; i < target->state->state.size(); ++i) ic.push_back({});
+            chainICs.push_back(std::make_pair(ic, 1));
+        }
+        nChain = chainICs.size();
+    }
+
+    /* mcmc.h:1468-1512 */
+    void run_all(size_t nSteps, size_t thinning, Float stepsizefac, int /*nThread*/) {
+        for (auto& s : stepsizes) s *= stepsizefac;
+        run_impl((int)nSteps, 0, (int)thinning, true);
+    }
+    /* mcmc.h:1513-1553 */
+    void run_all_adjust(size_t nSteps, size_t nAdjust, size_t thinning, int /*nThread*/) {
+        run_impl((int)nSteps, (int)nAdjust, (int)thinning, false);
+        if (nRun > 0) stepsizes = {R.fss[0]};
+        while (stepsizes.size() < target->state->state.size()) stepsizes.push_back(1);
+    }
+    /* mcmc.h:1555-1565 (the reference's bare `throw;` terminates; an exception is kinder) */
+    MetropolisChain& get_chain(size_t i) {
+        if (nRun == 0) {
+            std::cout << "ChainManager::get_chain: Requested chain " << i << "of the manager, but no valid chain is present. call ChainManager::run_chains first!\n";
+            throw std::out_of_range("ChainManager::get_chain: no chains");
+        }
+        if (nRun <= i) {
+            std::cout << "ChainManager::get_chain: Requested chain " << i << "of the manager, but only up to " << nRun << " chains are present. Valid indices up to " << nRun - 1 << " only!\n";
+            throw std::out_of_range("ChainManager::get_chain: index");
+        }
+        return materialize(i);
+    }
+    /* mcmc.h:1574-1596 */
+    void reevaluate_all(std::shared_ptr<State> state, int nBurnin, bool recordSamples, bool writeSamplesToDisk, int /*nThread*/) {
+        for (size_t i = 0; i < nRun; ++i) {
+            std::cout << "Reevaluating chain with id = " << i << "." << std::endl;
+            MetropolisChain& c = materialize(i);
+            c.recordSamples = recordSamples;
+            c.writeSamplesToDisk = writeSamplesToDisk;
+            c.reevaluate(state->deep_copy(), nBurnin);
+        }
+        std::cout << "Reevaluation completed." << std::endl << std::endl;
+    }
+    size_t n_chains() const { return chainICs.size(); }
+    /* bulk views of the last run, chain-major: loglikes [n][nSaved], saved sample s [n][dim] */
+    const std::vector<Float>& all_loglikes() const { return R.lls; }
+    const std::vector<Float>& all_final_params() const { return R.params; }
+    const std::vector<Float>& saved_sample(int s) const { return R.saved.at(s); }
+    int n_saved() const { return R.nSaved; }
+    int n_dim() const { return (int)R.dim; }
+    int chain_weight(size_t i) const { return chainICs.at(i).second; }
+    /* acceptance counts, step sizes ... of the last run, for diagnostics */
+    std::vector<Float> last_diagnostics;
+
+protected:
+    std::shared_ptr<Target> target;
+    size_t nChain = 1;
+    std::vector<std::pair<ICs, int>> chainICs;
+
+    /* evaluates log p_target(candidate) - oldlogprob in one batch, then bootstraps */
+    void build_from_candidates(pcg32& rnd, const std::vector<ICs>& cand, const std::vector<Float>& oldlogprob) {
+        DiseaseSpread* ds = target->state->disease();
+        Engine eng(*ds, target->state->prior(), target->spec());
+        const size_t n = cand.size(), dim = (size_t)eng.dim;
+        std::vector<Float> flat(n * dim), ll(n * 2);
+        for (size_t i = 0; i < n; ++i) {
+            if (cand[i][0].size() != dim) throw std::invalid_argument("ChainManager: candidate with wrong dimension");
+            std::copy(cand[i][0].begin(), cand[i][0].end(), flat.begin() + i * dim);
+        }
+        hip_check(mcmc_hip_eval(eng.ctx, (int64_t)n, flat.data(), ll.data()), "mcmc_hip_eval");
+        std::vector<std::pair<ICs, Float>> trial;
+        for (size_t i = 0; i < n; ++i) {
+            const Float prob = std::log(target->weight()) + target->beta(0) * (ll[2 * i] + ll[2 * i + 1]);
+            if (!std::isnan(prob) && !std::isinf(prob)) trial.push_back(std::make_pair(cand[i], prob - oldlogprob[i]));
+        }
+        if (trial.empty()) throw std::runtime_error("ChainManager: no candidate has a finite log probability");
+        bootstrap(rnd, trial);
+    }
+
+    /* mcmc.h:1599-1650: draw nChain distinct candidates from the discrete distribution of
+     * their probabilities; a candidate drawn again raises its chain's weight instead */
+    void bootstrap(pcg32& rnd, std::vector<std::pair<ICs, Float>>& trialChainICs) {
+        std::vector<double> discreteCDF;
+        double total = 0.0;
+        double maxsofar = -1e20;
+        for (auto& t : trialChainICs) if (t.second > maxsofar) maxsofar = t.second;
+        std::cout << "Selecting " << nChain << " chains according to the target density." << std::endl;
+        std::cout << "Highest log probability in set: " << maxsofar << "\n";
+        for (auto& t : trialChainICs) { t.second = std::exp(t.second - maxsofar); total += t.second; }
+        discreteCDF.push_back(trialChainICs[0].second);
+        for (size_t i = 1; i < trialChainICs.size(); ++i) discreteCDF.push_back(discreteCDF[i - 1] + trialChainICs[i].second);
+        discreteCDF.back() = 1.000001 * total;
+        std::map<size_t, size_t> old2new;
+        /* the reference loops until nChain DISTINCT candidates are found, which never ends
+         * when fewer exist; stop after a bounded number of draws instead */
+        const size_t maxDraws = 1000 * std::max<size_t>(nChain, 1) + 1000;
+        size_t draws = 0;
+        for (size_t i = 0; i < nChain && draws < maxDraws; ++i, ++draws) {
+            double x = rnd.nextDouble() * total;
+            auto iter = std::upper_bound(discreteCDF.begin(), discreteCDF.end(), x);
+            size_t idx = iter - discreteCDF.begin();
+            std::cout << "Relative loglikelihood of chain drawn is " << std::log(trialChainICs[idx].second) << "\n";
+            if (old2new.find(idx) == old2new.end()) {
+                chainICs.push_back(std::make_pair(trialChainICs[idx].first, 1));
+                old2new[idx] = chainICs.size() - 1;
+            } else {
+                std::cout << "Note: same chain " << old2new[idx] << " that has been picked " << chainICs[old2new[idx]].second
+                          << " times was picked again. New chain weight: " << chainICs[old2new[idx]].second + 1 << std::endl;
+                chainICs[old2new[idx]].second += 1;
+                --i;
+            }
+        }
+        std::cout << "Selection completed." << std::endl << std::endl;
+    }
+
+    /* what the last batched run recorded, for all chains; a MetropolisChain object (with its
+     * own deep-copied Target, mcmc.h:1479,1520) is only built when somebody asks for it */
+    struct Results {
+        size_t n = 0, dim = 0;
+        int nSaved = 0;
+        std::vector<Float> lls, params, mean, fll, fss;
+        std::vector<int32_t> acc;
+        std::vector<std::vector<Float>> saved;
+    } R;
+    size_t nRun = 0;
+    std::map<size_t, MetropolisChain> chains;
+
+    MetropolisChain& materialize(size_t i) {
+        auto it = chains.find(i);
+        if (it != chains.end()) return it->second;
+        const size_t dim = R.dim;
+        const int nSaved = R.nSaved;
+        std::shared_ptr<Target> tar = target->deep_copy();
+        MetropolisChain c(tar, (int)i + 1);
+        c.recordSamples = false;
+        c.weight = chainICs[i].second;
+        c.rec.loglikes.assign(R.lls.begin() + i * nSaved, R.lls.begin() + (i + 1) * nSaved);
+        for (int s = 0; s < nSaved; ++s) c.rec.ics.emplace_back(R.saved[s].begin() + i * dim, R.saved[s].begin() + (i + 1) * dim);
+        c.rec.mean.assign(R.mean.begin() + i * dim, R.mean.begin() + (i + 1) * dim);
+        c.rec.finalParams.assign(R.params.begin() + i * dim, R.params.begin() + (i + 1) * dim);
+        c.rec.finalLL[0] = R.fll[2 * i]; c.rec.finalLL[1] = R.fll[2 * i + 1];
+        c.rec.stepsize = R.fss[i];
+        c.rec.nAccept = R.acc[i];
+        DiseaseSpread* cds = tar->state->disease();
+        cds->unpack(c.rec.finalParams.data());
+        cds->loglike = R.fll[2 * i];
+        cds->stepsizeCorrectionFac = R.fss[i];
+        if (tar->state->prior()) tar->state->prior()->loglike = R.fll[2 * i + 1];
+        return chains.emplace(i, std::move(c)).first->second;
+    }
+
+    void run_impl(int nSteps, int nAdjust, int thinning, bool useStepsizes) {
+        chains.clear();
+        nRun = 0;
+        std::string why;
+        if (!target->state || !target->state->supported(&why)) { std::cout << "ChainManager: " << why << ".\n"; return; }
+        if (thinning < 1) { std::cout << "ChainManager: thinning must be at least 1.\n"; return; }
+        const size_t n = chainICs.size();
+        if (n == 0) { std::cout << "ChainManager: no initial conditions.\n"; return; }
+        DiseaseSpread* ds = target->state->disease();
+        Engine eng(*ds, target->state->prior(), target->spec());
+        const size_t dim = (size_t)eng.dim;
+        std::vector<Float> flat(n * dim);
+        for (size_t i = 0; i < n; ++i) std::copy(chainICs[i].first[0].begin(), chainICs[i].first[0].end(), flat.begin() + i * dim);
+        /* run_all applies the manager's step sizes, run_all_adjust starts from the target
+         * state's own (mcmc.h:1483 vs 1523) */
+        const Float ss0 = useStepsizes ? (stepsizes.empty() ? 1.0 : stepsizes[0]) : ds->stepsizeCorrectionFac;
+        std::vector<Float> ss(n, ss0);
+        hip_check(mcmc_hip_set_chains(eng.ctx, (int64_t)n, flat.data(), ss.data(), nullptr, 1), "mcmc_hip_set_chains");
+        {
+            std::vector<Float> ll(n * 2);
+            hip_check(mcmc_hip_get_loglike(eng.ctx, ll.data()), "mcmc_hip_get_loglike");
+            for (size_t i = 0; i < n; ++i)
+                std::cout << "Initialized chain " << i << " with true loglikelihood = " << ll[2 * i] + ll[2 * i + 1] << "\n";
+        }
+        /* the parameter samples are what the reference keeps as `ics` of every saved point
+         * (mcmc.h:1042-1045) even though recordSamples is forced off (mcmc.h:1490,1530) */
+        hip_check(mcmc_hip_run(eng.ctx, nSteps, 0, nAdjust, thinning, 1, 1), "mcmc_hip_run");
+        const int nSaved = mcmc_hip_n_saved(nSteps, 0, nAdjust, thinning);
+        /* bulk download, then split per chain */
+        R = Results{};
+        R.lls.assign(n * (size_t)std::max(nSaved, 1), 0); R.params.assign(n * dim, 0); R.mean.assign(n * dim, 0);
+        R.fll.assign(n * 2, 0); R.fss.assign(n, 0); R.acc.assign(n, 0);
+        if (nSaved > 0) hip_check(mcmc_hip_get_loglikes(eng.ctx, R.lls.data()), "mcmc_hip_get_loglikes");
+        hip_check(mcmc_hip_get_params(eng.ctx, R.params.data()), "mcmc_hip_get_params");
+        hip_check(mcmc_hip_get_mean(eng.ctx, R.mean.data()), "mcmc_hip_get_mean");
+        hip_check(mcmc_hip_get_loglike(eng.ctx, R.fll.data()), "mcmc_hip_get_loglike");
+        hip_check(mcmc_hip_get_stepsizes(eng.ctx, R.fss.data()), "mcmc_hip_get_stepsizes");
+        hip_check(mcmc_hip_get_accept_counts(eng.ctx, R.acc.data()), "mcmc_hip_get_accept_counts");
+        R.saved.assign(nSaved, std::vector<Float>(n * dim));
+        for (int s = 0; s < nSaved; ++s) hip_check(mcmc_hip_get_sample_all(eng.ctx, s, R.saved[s].data()), "mcmc_hip_get_sample_all");
+        last_diagnostics.assign(4 + 2 * dim, 0);
+        hip_check(mcmc_hip_diagnostics(eng.ctx, last_diagnostics.data()), "mcmc_hip_diagnostics");
+        R.n = n; R.dim = dim; R.nSaved = nSaved;
+        nRun = n;
+        std::cout << "Chain runs completed." << std::endl << std::endl;
+    }
+};
+
+}  // namespace mcmc_amd

@@ -1,0 +1,160 @@
+"""GPU tests of the pybind11 module `mcmc` (Python surface of the reference for the covid
+path): the flow of notebooks/covid.ipynb cells 3-7 -- data, params, DiseaseSpread,
+SmoothnessPrior, State, TempTarget, Chain.run, ChainManager.run_all -- gives, bit for bit,
+what the CPU oracle gives for the same chain ids and inputs."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ABI_CURVE_ORDER, ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "mcmc_amd", "pymod"))
+mcmc = pytest.importorskip("mcmc", reason="build it with `make -C mcmc_amd/pymod`")
+
+from mcmc_amd import covid_config as CC  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+N_TRAJ = 200_000
+DISC = np.array([[1, 9, 12, 29], [1, .6, .5, .4], [1, 1, 1, 1]], dtype=float)
+
+
+def _setup(T=1.0, cooling=None):
+    """covid.ipynb cells 3-4 with the Italy series that is hard-coded there."""
+    deaths = CC.ITALY_DEATHS
+    sigma = CC.sigma_recipe(deaths)
+    data = mcmc.DiseaseData(np.array([deaths, sigma]), DISC)
+    data.initialBetaMild, data.initialBetaHigh, data.initialDelay = 0.8, 2.5, 23.0
+    p = mcmc.DiseaseParams()
+    dp = CC.ipynb_disease_params()
+    for k, v in dp.items():
+        setattr(p, k, v)
+    ds = mcmc.DiseaseSpread(data, p, 60000000, 7500.0, 100.0, 40, 60, N_TRAJ)
+    nB = len(deaths) - data.fixBehaviorInAdvance
+    state = mcmc.State()
+    state.add(ds)
+    state.add(mcmc.SmoothnessPrior("behavior", 50.0, float(nB)))
+    state.init()
+    target = mcmc.CoolingTarget(*cooling) if cooling else mcmc.TempTarget(T)
+    target.set_posterior(state)
+    # the same model for the oracle (FMA contraction: the host side's default)
+    R11 = np.zeros((O.NCURVES, 500))
+    R11[ABI_CURVE_ORDER] = ds.response_table()
+    kind = dict(target_kind="cooling", target_slope=cooling[0], target_Tinit=cooling[1]) if cooling else \
+        dict(target_kind="temp", target_T=T)
+    cfg = CC.make_config(deaths, sigma, disease_params=dp, initial_beta_mild=0.8, initial_beta_high=2.5,
+                         initial_delay=23.0, contract=1, **kind)
+    m = O.Model(cfg, R11, contract=1)
+    tgt = O.make_target("cooling", 1.0, *cooling) if cooling else O.make_target("temp", T)
+    return data, p, ds, state, target, cfg, m, tgt
+
+
+def test_state_init_evaluates_on_the_gpu():
+    data, p, ds, state, target, cfg, m, tgt = _setup()
+    x0 = CC.initial_params(cfg)
+    ll, curves = m.eval(x0, curves=True)
+    assert state.loglike() == ll + m.prior(x0)
+    allc = state.get_all()
+    assert set(allc) == set(ds.get_names())
+    assert np.array_equal(allc["dead"], curves[7]) and np.array_equal(allc["totalBehavior"], curves[8])
+    assert allc["delay"] == [23.0]
+
+
+@pytest.mark.parametrize("cooling", [None, (2.0, 5.0)])
+def test_chain_run_equals_oracle_chain(cooling):
+    data, p, ds, state, target, cfg, m, tgt = _setup(T=2.0, cooling=cooling)
+    x0 = CC.initial_params(cfg)
+    chain = mcmc.Chain(target, 0)                      # id 0 like test.cpp:36
+    chain.run(60, 4, 3, 5)
+    oc = O.OracleChain(m, 0, x0)
+    ll, samples, mean = oc.run(tgt, 60, 4, 3, 5, record=True, mean=True)
+    assert np.array_equal(chain.get_loglikes(), ll)
+    nB, nD = cfg["nB"], cfg["n_disc"]
+    assert np.array_equal(chain.get_samples("behavior"), samples[:, :nB])
+    assert np.array_equal(chain.get_samples("discontinuousVals"), samples[:, nB:nB + nD])
+    assert np.array_equal(chain.get_samples("delay"), samples[:, -1:])
+    assert np.array_equal(chain.get_mean("betaMild"), mean[nB + nD:nB + nD + 1])
+    assert np.array_equal(chain.get_mean("behavior"), mean[:nB])
+    assert np.array_equal(chain.get_weights(), np.ones(len(ll)))
+    # derived coords of the saved samples are computed on request (compute_derived_late)
+    dead = chain.get_samples("dead")
+    want = np.array([m.eval(s, curves=True)[1][7] for s in samples])
+    assert dead.shape == (len(ll), cfg["size"]) and np.array_equal(dead, want)
+    # the target's state now is the chain's end state, step size included
+    assert ds.getCoords("delay") == [oc.x[-1]] and ds.stepsizeCorrectionFac == oc.c.stepsize
+    assert state.loglike() == oc.ll[0] + oc.ll[1]
+    # reevaluate drops burn-in points (mcmc.h:1160-1161)
+    chain.reevaluate(state, 2)
+    assert np.array_equal(chain.get_loglikes(), ll[2:])
+    assert np.array_equal(chain.get_samples("betaHigh"), samples[2:, -2:-1])
+
+
+def test_chain_manager_runs_all_chains_in_one_batch(tmp_path, monkeypatch):
+    data, p, ds, state, target, cfg, m, tgt = _setup(T=1.0)
+    x0 = CC.initial_params(cfg)
+    cm = mcmc.ChainManager(target, 5)
+    cm.run_all(30, 2, 3, 4)                # bound to run_all_adjust(nSteps, nAdjust, thinning, nThread), test.cpp:124
+    for i in (0, 3, 4):
+        oc = O.OracleChain(m, i + 1, x0)   # chain i draws pcg32(0, i+1), mcmc.h:1527
+        ll, samples, _ = oc.run(tgt, 30, 0, 2, 3, record=True)
+        c = cm.get_chain(i)
+        assert np.array_equal(c.get_loglikes(), ll)
+        assert c.weight == 1
+    assert cm.all_loglikes().shape == (5, len(ll))
+    oc0 = O.OracleChain(m, 1, x0)
+    oc0.run(tgt, 30, 0, 2, 3, record=False)
+    assert cm.stepsizes[0] == oc0.c.stepsize          # stepsizes = chains[0]'s, mcmc.h:1550
+    with pytest.raises(IndexError):
+        cm.get_chain(7)
+    # samples are available after reevaluate_all (run_all records only the points, mcmc.h:1490)
+    monkeypatch.chdir(tmp_path)
+    cm.reevaluate_all(state, 1, True, True, 1)
+    c = cm.get_chain(3)
+    oc3 = O.OracleChain(m, 4, x0)
+    _, samples3, _ = oc3.run(tgt, 30, 0, 2, 3, record=True)
+    assert np.array_equal(c.get_samples("delay"), samples3[1:, -1:])
+    txt = open(tmp_path / "samples4.txt").read()
+    assert txt.startswith("chainweight = 1") and "loglike" in txt and "\ndead " in txt
+    # run_all_adjust is bound to run_all(nSteps, thinning, stepsizefac, nThread), test.cpp:125
+    ss = cm.stepsizes[0]
+    cm.run_all_adjust(10, 2, 0.5, 1)
+    oc = O.OracleChain(m, 2, x0, stepsize=ss * 0.5)
+    ll2, _, _ = oc.run(tgt, 10, 0, 0, 2, record=False)
+    assert np.array_equal(cm.get_chain(1).get_loglikes(), ll2)
+
+
+def test_reservoir_and_generator_constructors():
+    data, p, ds, state, target, cfg, m, tgt = _setup(T=1.0)
+    # reservoir: DiseaseSpread has no sampleInitialConditions (mcmc.h:112-114), so all
+    # candidates coincide; the bootstrap then finds one distinct state with weight nChain
+    cm = mcmc.ChainManager(target, 6, 1)
+    assert cm.n_chains() == 1 and cm.chain_weight(0) == 1
+    # generator chain at T=10 seeds chains for the T=1 target (notebooks/test2.ipynb flow)
+    hot = mcmc.TempTarget(10.0)
+    hot.set_posterior(state)
+    gen = mcmc.Chain(hot, 0)
+    gen.run(200, 0, 2, 10)
+    cm2 = mcmc.ChainManager(gen, target, 2)
+    assert cm2.n_chains() == 2 and sum(cm2.chain_weight(i) for i in range(2)) >= 2
+    cm2.run_all(10, 0, 5, 1)
+    assert cm2.all_loglikes().shape == (2, 2) and np.all(np.isfinite(cm2.all_loglikes()))
+    # the bootstrap picks follow the discrete CDF of exp(new - old) with pcg32(0,0) draws
+    lls = gen.get_loglikes()
+    pts = np.hstack([gen.get_samples(k) for k in ("behavior", "discontinuousVals", "betaMild", "betaHigh", "delay")])
+    new = np.array([m.eval(x) + m.prior(x) for x in pts])
+    w = np.exp((new - lls) - np.max(new - lls))
+    cdf = np.cumsum(w)
+    cdf[-1] = 1.000001 * w.sum()
+    total = w.sum()
+    r = O.Rng(0, 0)
+    picks = []
+    while len(picks) < 2:
+        idx = int(np.searchsorted(cdf, r.next_double() * total, side="right"))
+        if idx not in picks:
+            picks.append(idx)
+    first = mcmc.ChainManager(gen, target, 2)
+    first.run_all(1, 0, 1, 1)              # one step, one saved point = the initial conditions
+    assert np.array_equal(first.saved_sample(0), pts[picks])
