@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU)
     ap.add_argument("--contract", type=int, default=int(os.environ.get("MCMC_BENCH_CONTRACT", "1")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # rehearsal knobs: several ranks on ONE card need the gloo backend and a fixed device
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--device", type=int, default=None, help="HIP ordinal for every rank (default: LOCAL_RANK)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -96,11 +99,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     import torch
+    device = args.device if args.device is not None else (local_rank if world > 1 else 0)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = local_rank if world > 1 else 0
+        torch.cuda.set_device(device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
     if H.lib().mcmc_hip_device_count() < 1:
         raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
 
@@ -124,7 +130,7 @@ def main():
     dt = time.perf_counter() - t0
     t_after = s.last_timing()
     if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -150,7 +156,7 @@ def main():
             "value": value, "unit": "MH steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "covid.h model, 65536 independent chains per GPU, 365-day synthetic "
+            "config": {"workload": f"covid.h model, {n_chains} independent chains per GPU, 365-day synthetic "
                                    "series, chain-sharded (BASELINE.json configs[2])",
                        "chains_per_gpu": n_chains, "n_data": N_DATA, "dim": cfg["dim"],
                        "size": cfg["size"], "fp_contract": "fma" if args.contract else "strict",
