@@ -635,14 +635,31 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
          * pass's in the second (multadd, covid.h:484).  A streaming loop over two per-lane
          * rows and the LDS-resident observations. */
         {
+            /* eight data days per trip: all loads of a trip are requested before the first
+             * term is formed, so one memory round trip is paid per eight days, not per day */
             const double* d1_u = B.d1s_u;
             const double* d0_u = B.d1s_u + M.nData * MCMC_WAVE;
-#pragma unroll 4
-            for (int di = 0; di < M.nData; ++di) {
-                double dead = d1_u[di * MCMC_WAVE + lane];
-                if (shift == 0) dead = dead + d0_u[di * MCMC_WAVE + lane];
-                const double delta = dead - lds.deaths[di];
-                loglike += w * (-0.5 * delta * delta / lds.sigma2[di]);
+            constexpr int LB = 8;
+#pragma unroll 1
+            for (int d0 = 0; d0 < M.nData; d0 += LB) {
+                double dv[LB];
+#pragma unroll
+                for (int j = 0; j < LB; ++j) dv[j] = d1_u[min(d0 + j, M.nData - 1) * MCMC_WAVE + lane];
+                if (shift == 0) {
+                    double d2[LB];
+#pragma unroll
+                    for (int j = 0; j < LB; ++j) d2[j] = d0_u[min(d0 + j, M.nData - 1) * MCMC_WAVE + lane];
+#pragma unroll
+                    for (int j = 0; j < LB; ++j) dv[j] = dv[j] + d2[j];
+                }
+#pragma unroll
+                for (int j = 0; j < LB; ++j) {
+                    const int di = d0 + j;
+                    if (di < M.nData) {
+                        const double delta = dv[j] - lds.deaths[di];
+                        loglike += w * (-0.5 * delta * delta / lds.sigma2[di]);
+                    }
+                }
             }
         }
         pc.stamp(PH_LOGLIKE);
@@ -679,8 +696,9 @@ __device__ inline void load_lane_scalars(const DevModel& M, const double* x_u, u
  * writes the complete proposal vector xp, returns its scalars in lp and whether the
  * behaviour function changed (only then the smoothness prior has to be re-evaluated).
  */
-__device__ inline bool propose(const DevModel& M, Pcg32& rnd, const double* xc_u, double* xp_u,
-                               unsigned lane, double stepsize, LaneScalars& lp) {
+__device__ inline bool propose(const DevModel& M, Pcg32& rnd, const double* __restrict__ xc_u,
+                               double* __restrict__ xp_u, unsigned lane, double stepsize, LaneScalars& lp,
+                               double& priorOut) {
     load_lane_scalars(M, xc_u, lane, lp);
     double disc[MCMC_MAXDISC];
 #pragma unroll
@@ -744,19 +762,44 @@ __device__ inline bool propose(const DevModel& M, Pcg32& rnd, const double* xc_u
         A = sfmin * 0.1 * (rnd.next_double() - 0.5);
         if (big5) A += sfmin * (rnd.next_double() - 0.5);
     }
-    /* write the proposal vector */
+    /* write the proposal vector; where some lane's behaviour function changes, the
+     * smoothness prior of the proposal (mcmc.h:197-214) is summed on the way, from the
+     * values just written: same terms, same order as a pass of its own over them */
+    priorOut = 0.0;
     if (__any(doB)) {
-#pragma unroll 2
-        for (int i = 0; i < M.nB; ++i) {
-            double v = xc_u[i * MCMC_WAVE + lane];
-            if (doB) {
-                v += A * (mcmc_cos(omega * (double)i) - 1);
-                v = bound_reflect(v, 0.0, 2.0);
+        const int n = M.nB;
+        const double dx = M.smoothL / (double)n;
+        double loglike = 0;
+        double fm = 0, f0 = 0;
+        constexpr int PB = 4;                /* loads of a trip are requested together */
+#pragma unroll 1
+        for (int i0 = 0; i0 < n; i0 += PB) {
+            double vv[PB];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) vv[j] = xc_u[min(i0 + j, n - 1) * MCMC_WAVE + lane];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const int i = i0 + j;
+                if (i < n) {
+                    double v = vv[j];
+                    if (doB) {
+                        v += A * (mcmc_cos(omega * (double)i) - 1);
+                        v = bound_reflect(v, 0.0, 2.0);
+                    }
+                    xp_u[i * MCMC_WAVE + lane] = v;
+                    if (i >= 2) {
+                        const double dd = v + fm - 2 * f0;
+                        loglike -= dd * dd / dx / dx / dx;
+                    }
+                    fm = f0;
+                    f0 = v;
+                }
             }
-            xp_u[i * MCMC_WAVE + lane] = v;
         }
+        loglike *= M.smoothLs * M.smoothLs / M.smoothL;
+        priorOut = loglike;
     } else {
-#pragma unroll 4
+#pragma unroll 8
         for (int i = 0; i < M.nB; ++i) xp_u[i * MCMC_WAVE + lane] = xc_u[i * MCMC_WAVE + lane];
     }
 #pragma unroll
@@ -881,18 +924,15 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
 
         pc.stamp(PH_RECORD);
         LaneScalars lp;
-        const bool behChanged = propose(M, rnd, xc_u, xp_u, lane, stepsize, lp);
+        double llpNew;
+        const bool behChanged = propose(M, rnd, xc_u, xp_u, lane, stepsize, lp, llpNew);
         pc.stamp(PH_PROPOSE);
         const double llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, pairs, pc);
         double llp = 0.0;
         double delta = 0;                                           /* mcmc.h:604-606 */
         delta += -llModel + llm;
         if (M.hasPrior) {
-            llp = llPrior;
-            if (__any(behChanged)) {
-                const double v = eval_prior(M, xp_u, lane);
-                if (behChanged) llp = v;
-            }
+            llp = behChanged ? llpNew : llPrior;     /* unchanged behaviour: the prior keeps its value */
             delta += -llPrior + llp;
         }
         pc.stamp(PH_PRIOR);
@@ -901,9 +941,15 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
         const double u = (double)rnd.next_float();
         const bool accept = u < 1.0 * mcmc_exp(delta);              /* mcmc.h:776 */
         if (__any(accept)) {                                        /* State::accept, mcmc.h:653-661 */
-            for (int k = 0; k < S.dim; ++k) {
-                const double v = xp_u[k * MCMC_WAVE + lane];
-                if (accept) xcw_u[k * MCMC_WAVE + lane] = v;
+            constexpr int AB = 8;
+#pragma unroll 1
+            for (int k0 = 0; k0 < S.dim; k0 += AB) {
+                double vv[AB];
+#pragma unroll
+                for (int j = 0; j < AB; ++j) vv[j] = xp_u[min(k0 + j, S.dim - 1) * MCMC_WAVE + lane];
+#pragma unroll
+                for (int j = 0; j < AB; ++j)
+                    if (accept && k0 + j < S.dim) xcw_u[(k0 + j) * MCMC_WAVE + lane] = vv[j];
             }
         }
         if (accept) {
