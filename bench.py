@@ -8,6 +8,8 @@ One "step" = one Target::step (mcmc.h:750-783) for EVERY chain of the workload: 
 compartment-model forward simulation, likelihood, prior, accept/reject.  Workload =
 BASELINE.json configs[2]: covid.h model, 65536 independent chains PER GPU, 365-day synthetic
 series, chain-sharded by chain-id range (weak scaling, no collective on the data path).
+The chains first run `--adjust` iterations of the reference's step-size adaptation (untimed,
+like the adjust phase that precedes sampling in MetropolisChain::run), then W warm-up steps.
 All inputs are resident in HBM before the timed region.  Arithmetic is FP64 as in the
 reference (`using Float = double`, mcmc.h:43).
 
@@ -60,7 +62,7 @@ def build_workload(device, n_chains, first_chain_id, contract, n_data=N_DATA):
     return cfg, R, xs, sampler
 
 
-def cpu_baseline(cfg, R10, xs, contract, seconds=20.0):
+def cpu_baseline(cfg, R10, xs, stepsizes, contract, seconds=20.0):
     """The oracle (a CPU port of the same path, oracle/mcmc_oracle.c) timed on this box's
     host cores on a bounded sample of the same workload.  Reported, not the target."""
     from oracle import oracle as O
@@ -72,12 +74,13 @@ def cpu_baseline(cfg, R10, xs, contract, seconds=20.0):
     tgt = O.make_target("temp", 1.0)
     threads = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 64))
     n_chains = 4 * threads
-    cal = O.run_chains(m, tgt, xs[:n_chains], 1.0, 4, 0, 0, 1000, n_threads=threads)
+    ss = stepsizes[:n_chains]
+    cal = O.run_chains(m, tgt, xs[:n_chains], ss, 4, 0, 0, 1000, n_threads=threads)
     per_step = cal["wall"] / 4
     n_samples = int(max(8, min(40000, seconds / max(per_step, 1e-6))))
-    res = O.run_chains(m, tgt, xs[:n_chains], 1.0, n_samples, 0, 0, 1000, n_threads=threads)
+    res = O.run_chains(m, tgt, xs[:n_chains], ss, n_samples, 0, 0, 1000, n_threads=threads)
     return {"value": res["steps"] / res["wall"], "unit": "MH steps/s", "cores": threads, "kind": "port",
-            "sample": f"{n_chains} chains x {n_samples} steps of the same 365-day workload "
+            "sample": f"{n_chains} chains x {n_samples} steps of the same 365-day workload from the same adapted state "
                       f"(oracle/mcmc_oracle.c, lean table, {threads} pthreads, {res['wall']:.1f} s)"}
 
 
@@ -88,6 +91,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU)
     ap.add_argument("--contract", type=int, default=int(os.environ.get("MCMC_BENCH_CONTRACT", "1")))
+    ap.add_argument("--adjust", type=int, default=int(os.environ.get("MCMC_BENCH_ADJUST", "25")),
+                    help="adjust-phase iterations (20 MH steps each, mcmc.h:1083-1119) run untimed before the warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     # rehearsal knobs: several ranks on ONE card need the gloo backend and a fixed device
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
@@ -120,7 +125,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.adjust > 0:
+        s.run(0, 0, args.adjust, 1000000)                # step-size adaptation only, nothing recorded
     s.step(args.warmup, 1.0, True)
+    cpu_start = (s.params()[:256].copy(), s.stepsizes()[:256].copy()) if rank == 0 else None
     s.pair_count(reset=True)
     t_before = s.last_timing()
     sync()
@@ -160,6 +168,7 @@ def main():
                                    "series, chain-sharded (BASELINE.json configs[2])",
                        "chains_per_gpu": n_chains, "n_data": N_DATA, "dim": cfg["dim"],
                        "size": cfg["size"], "fp_contract": "fma" if args.contract else "strict",
+                       "adjust_iterations_before_timing": args.adjust,
                        "parallelism": f"chain-shard x{world}"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP64_VECTOR_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VECTOR_TFLOPS,
@@ -170,7 +179,7 @@ def main():
                          "frac_of_fp32_vector_peak": achieved / PEAK_FP32_VECTOR_TFLOPS},
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(cfg, R, xs, args.contract)
+            cb = cpu_baseline(cfg, R, cpu_start[0], cpu_start[1], args.contract)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = value / cb["value"]
         print(json.dumps(out), flush=True)

@@ -393,3 +393,35 @@ def test_pair_count_is_the_survey_work_unit(R11, R10):
     lo = 64 * sum((size - 5 - k) * (size - 5 - k + 1) // 2 for k in (0, 1))
     assert abs(got - lo) <= 64 * 4 * size          # a changed delay moves start by at most +-1
     s.close()
+
+
+def test_posterior_summaries_equal_the_cpu_sampler(R11, R10):
+    """north_star: "posterior means and quantiles within a stated tolerance of the reference
+    CPU sampler".  The chains are bit-identical to the CPU oracle's, so the tolerance is ZERO:
+    means and 5/50/95 % quantiles of delay, betaMild, betaHigh and the breakpoint values over
+    32 chains x 300 saved points agree exactly."""
+    cfg = make_cfg(40, R11, contract=1, **SMALL)
+    m = O.Model(cfg, R11, contract=1)
+    n = 32
+    xs = perturbed(cfg, n, 0.05)
+    s = H.CovidSampler(cfg, R10)
+    s.set_chains(xs, first_chain_id=1)
+    ns, nb, na, th = 600, 0, 10, 2
+    s.run(ns, nb, na, th, record_samples=True)
+    k0 = cfg["nB"]
+    gpu = np.array([s.samples(c, k0, cfg["n_disc"] + 3) for c in range(n)])
+    tgt = O.make_target("temp", 1.0)
+    cpu = []
+    for c in range(n):
+        oc = O.OracleChain(m, c + 1, xs[c])
+        _, samples, _ = oc.run(tgt, ns, nb, na, th, record=True)
+        cpu.append(samples[:, k0:])
+    cpu = np.array(cpu)
+    assert gpu.shape == cpu.shape == (n, s.n_saved, cfg["n_disc"] + 3)
+    post_g, post_c = gpu[:, 20:].reshape(-1, gpu.shape[2]), cpu[:, 20:].reshape(-1, cpu.shape[2])
+    assert np.array_equal(post_g.mean(axis=0), post_c.mean(axis=0))
+    for q in (5, 50, 95):
+        assert np.array_equal(np.percentile(post_g, q, axis=0), np.percentile(post_c, q, axis=0))
+    # the sampler moved: not a trivially constant trace
+    assert np.all(post_g.std(axis=0) > 0)
+    s.close()

@@ -6,11 +6,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+adjust = int(sys.argv[3]) if len(sys.argv) > 3 else 25
 cfg, R, xs, s = bench.build_workload(0, n, 1, 1)
+if adjust:
+    s.run(0, 0, adjust, 1000000)
 s.step(16, 1.0, True)
 s.phase_cycles(reset=True)
+import time
+t0 = time.perf_counter()
 s.step(steps, 1.0, True)
+dt = time.perf_counter() - t0
 ph = s.phase_cycles()
+print(f"{n * steps / dt / 1e6:.2f} M steps/s (stamped build), acceptance {s.accept_counts().mean():.1f} per chain since reset")
 counts = {k: ph.pop(k) for k in ("n_chunks", "n_chunks_e")}
 tot = sum(ph.values())
 waves = (n + 63) // 64
