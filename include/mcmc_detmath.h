@@ -1,8 +1,9 @@
 /*
- * mcmc_detmath.h -- deterministic double-precision cos() and exp().
+ * mcmc_detmath.h -- deterministic double-precision cos(), exp() and log().
  *
  * Why this exists: the reference calls libm's std::cos (covid.h:619, the behaviour
- * proposal) and std::exp (mcmc.h:776, the acceptance test).  glibc's and the GPU's
+ * proposal), std::exp (mcmc.h:776, the acceptance test; test.h:93-96) and std::log
+ * (test.h:98).  glibc's and the GPU's
  * (ocml) implementations differ in the last bit for some arguments, which would make
  * the chain state on the GPU drift from a CPU run by an ulp and defeat bit-exact
  * comparison.  Both the HIP kernels and the CPU oracle therefore use the two functions
@@ -137,6 +138,66 @@ MCMC_HD double mcmc_exp(double x) {
     }
     return (y * mcmc_bits2d((uint64_t)(0x3ff + (k + 1000)) << 52)) *
            mcmc_bits2d((uint64_t)(0x3ff - 1000) << 52);
+}
+
+/*
+ * Deterministic log(x) (FourGaussians::eval, test.h:98).  log(0) = -inf, log(<0) = NaN,
+ * subnormals handled.  Argument reduction x = 2^k (1+f), log(1+f) by the classic minimax
+ * polynomial in s = f/(2+f).
+ */
+MCMC_HD double mcmc_log(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 two54 = 1.80143985094819840000e+16,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t bits = mcmc_d2bits(x);
+    int32_t hx = (int32_t)(bits >> 32);
+    uint32_t lx = (uint32_t)bits;
+    int32_t k = 0;
+    if (hx < 0x00100000) {                              /* x < 2^-1022 */
+        if (((hx & 0x7fffffff) | lx) == 0) return -mcmc_bits2d(0x7ff0000000000000ULL);
+        if (hx < 0) return (x - x) / (x - x);           /* NaN */
+        k -= 54;
+        x *= two54;
+        bits = mcmc_d2bits(x);
+        hx = (int32_t)(bits >> 32);
+    }
+    if (hx >= 0x7ff00000) return x + x;
+    k += (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    int32_t i = (hx + 0x95f64) & 0x100000;
+    bits = ((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32) | (bits & 0xffffffffULL);
+    x = mcmc_bits2d(bits);                              /* normalise x or x/2 */
+    k += (i >> 20);
+    const double f = x - 1.0;
+    const double dk = (double)k;
+    if ((0x000fffff & (2 + hx)) < 3) {                  /* |f| < 2^-20 */
+        if (f == 0.0) {
+            if (k == 0) return 0.0;
+            return dk * ln2_hi + dk * ln2_lo;
+        }
+        const double R = f * f * (0.5 - 0.33333333333333333 * f);
+        if (k == 0) return f - R;
+        return dk * ln2_hi - ((R - dk * ln2_lo) - f);
+    }
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    i = hx - 0x6147a;
+    const double w = z * z;
+    const int32_t j = 0x6b851 - hx;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    i |= j;
+    const double R = t2 + t1;
+    if (i > 0) {
+        const double hfsq = 0.5 * f * f;
+        if (k == 0) return f - (hfsq - s * (hfsq + R));
+        return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    if (k == 0) return f - s * (f - R);
+    return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
 }
 
 #endif /* MCMC_DETMATH_H */

@@ -818,4 +818,108 @@ int mcmc_hip_pair_count(mcmc_hip_ctx* c, double* pairs_out, int32_t reset) {
     return 0;
 }
 
+/* ------------------------------------------------------------------ toy targets ---- */
+static int toy_dim(int kind) { return kind == MCMC_TOY_MYLIKE1 ? 3 : kind == MCMC_TOY_FOURGAUSS ? 2 : -1; }
+
+int mcmc_hip_toy_dim(int32_t kind) {
+    const int d = toy_dim(kind);
+    return d > 0 ? d : fail(MCMC_HIP_EINVAL, "unknown toy target %d", kind);
+}
+
+static int toy_device(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(MCMC_HIP_ENODEVICE, "no HIP device visible: the hot path has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(MCMC_HIP_EINVAL, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+
+int mcmc_hip_toy_eval(int device, int32_t kind, double difficulty, int64_t n, const double* x, double* ll_out) {
+    const int dim = toy_dim(kind);
+    if (dim < 0 || n < 1 || !x || !ll_out) return fail(MCMC_HIP_EINVAL, "toy_eval: bad arguments");
+    if (int r = toy_device(device)) return r;
+    std::vector<double> soa((size_t)dim * n);
+    for (int64_t c = 0; c < n; ++c)
+        for (int k = 0; k < dim; ++k) soa[(size_t)k * n + c] = x[c * dim + k];
+    DevBuf<double> dx, dl;
+    if (int r = dx.alloc(soa.size())) return r;
+    if (int r = dl.alloc(n)) return r;
+    HIP_TRY(hipMemcpy(dx.p, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice));
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (kind == MCMC_TOY_MYLIKE1) hipLaunchKernelGGL(toy_eval_kernel<TOY_MYLIKE1>, dim3(grid), dim3(256), 0, 0, (const double*)dx.p, dl.p, (long long)n, difficulty);
+    else hipLaunchKernelGGL(toy_eval_kernel<TOY_FOURGAUSS>, dim3(grid), dim3(256), 0, 0, (const double*)dx.p, dl.p, (long long)n, difficulty);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(ll_out, dl.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target_kind, double target_T,
+                     double target_slope, double target_Tinit, int64_t n, const uint64_t* chain_ids,
+                     uint64_t first_chain_id, double* x, double* stepsizes, int32_t nSamples, int32_t nBurnin,
+                     int32_t nAdjust, int32_t thinning, double* loglikes_out, double* samples_out,
+                     int32_t* n_accept_out) {
+    const int dim = toy_dim(kind);
+    if (dim < 0 || n < 1 || !x || !stepsizes) return fail(MCMC_HIP_EINVAL, "toy_run: bad arguments");
+    if (nSamples < 0 || nBurnin < 0 || nAdjust < 0 || thinning < 1)
+        return fail(MCMC_HIP_EINVAL, "toy_run: need n_samples,n_burnin,n_adjust >= 0 and thinning >= 1");
+    if (target_kind < MCMC_TARGET_PLAIN || target_kind > MCMC_TARGET_COOLING) return fail(MCMC_HIP_EINVAL, "toy_run: unknown target_kind");
+    if (int r = toy_device(device)) return r;
+    mcmc_covid_config tc{};
+    tc.target_kind = target_kind; tc.target_T = target_T; tc.target_slope = target_slope; tc.target_Tinit = target_Tinit;
+    const int nIter = nSamples + nAdjust;
+    std::vector<double> betas((size_t)std::max(nIter, 1), 1.0);
+    for (int i = 0; i < nIter; ++i)
+        betas[i] = target_beta(tc, i < nAdjust ? (double)i / nAdjust : (double)(i - nAdjust) / nSamples);
+    const int nSaved = mcmc_hip_n_saved(nSamples, nBurnin, nAdjust, thinning);
+    std::vector<double> soa((size_t)dim * n);
+    std::vector<uint64_t> ids(n);
+    for (int64_t c = 0; c < n; ++c) {
+        ids[c] = chain_ids ? chain_ids[c] : first_chain_id + (uint64_t)c;
+        for (int k = 0; k < dim; ++k) soa[(size_t)k * n + c] = x[c * dim + k];
+    }
+    DevBuf<double> dx, dss, dbeta, dll, dsamp;
+    DevBuf<uint64_t> dids;
+    DevBuf<int> dacc;
+    if (int r = dx.alloc(soa.size())) return r;
+    if (int r = dss.alloc(n)) return r;
+    if (int r = dbeta.alloc(betas.size())) return r;
+    if (int r = dids.alloc(n)) return r;
+    if (int r = dacc.alloc(n)) return r;
+    if (loglikes_out && nSaved > 0) { if (int r = dll.alloc((size_t)nSaved * n)) return r; }
+    if (samples_out && nSaved > 0) { if (int r = dsamp.alloc((size_t)nSaved * dim * n)) return r; }
+    HIP_TRY(hipMemcpy(dx.p, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dss.p, stepsizes, n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dbeta.p, betas.data(), betas.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dids.p, ids.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (kind == MCMC_TOY_MYLIKE1)
+        hipLaunchKernelGGL(toy_run_kernel<TOY_MYLIKE1>, dim3(grid), dim3(256), 0, 0, dx.p, dss.p, (const uint64_t*)dids.p, (long long)n,
+                           difficulty, (const double*)dbeta.p, nSamples, nBurnin, nAdjust, thinning, dll.p, dsamp.p, dacc.p);
+    else
+        hipLaunchKernelGGL(toy_run_kernel<TOY_FOURGAUSS>, dim3(grid), dim3(256), 0, 0, dx.p, dss.p, (const uint64_t*)dids.p, (long long)n,
+                           difficulty, (const double*)dbeta.p, nSamples, nBurnin, nAdjust, thinning, dll.p, dsamp.p, dacc.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(soa.data(), dx.p, soa.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t c = 0; c < n; ++c)
+        for (int k = 0; k < dim; ++k) x[c * dim + k] = soa[(size_t)k * n + c];
+    HIP_TRY(hipMemcpy(stepsizes, dss.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (n_accept_out) HIP_TRY(hipMemcpy(n_accept_out, dacc.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (dll.p) {
+        std::vector<double> h((size_t)nSaved * n);
+        HIP_TRY(hipMemcpy(h.data(), dll.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t c = 0; c < n; ++c)
+            for (int s = 0; s < nSaved; ++s) loglikes_out[c * nSaved + s] = h[(size_t)s * n + c];
+    }
+    if (dsamp.p) {
+        std::vector<double> h((size_t)nSaved * dim * n);
+        HIP_TRY(hipMemcpy(h.data(), dsamp.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t c = 0; c < n; ++c)
+            for (int s = 0; s < nSaved; ++s)
+                for (int k = 0; k < dim; ++k) samples_out[((size_t)c * nSaved + s) * dim + k] = h[((size_t)s * dim + k) * n + c];
+    }
+    return 0;
+}
+
 }  // extern "C"

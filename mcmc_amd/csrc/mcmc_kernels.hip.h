@@ -1064,3 +1064,106 @@ __global__ __launch_bounds__(MCMC_WAVE) void diagnostics_kernel(DevModel M, Chai
         }
     }
 }
+
+/* ------------------------------------------------------------------ toy targets ---- */
+/* MyLike1 (test.h:14-67) and FourGaussians (test.h:69-136) under MetropolisChain::run
+ * (mcmc.h:1005-1138) with a one-likelihood State: one chain per lane, the whole run in one
+ * launch.  Chain-flat layouts: x [dim][n], recLL [slot][n], recS [slot][dim][n]. */
+enum { TOY_MYLIKE1 = 0, TOY_FOURGAUSS = 1 };
+
+template <int KIND>
+__device__ __forceinline__ double toy_loglike(const double (&x)[3], double difficulty) {
+    if constexpr (KIND == TOY_MYLIKE1) {
+        const double dp[2][3] = {{2, 2, 0}, {-2, -2, 0}};
+        double loglike = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) loglike -= (dp[i][j] - x[j]) * (dp[i][j] - x[j]) * 0.5;
+        return loglike;
+    } else {
+        const double a = x[0], y = x[1];
+        double loglike;
+        loglike = mcmc_exp(-difficulty * ((a + 0.5) * (a + 0.5) / (2 * 0.5 * 0.5) + (y + 1) * (y + 1) / (2 * 0.2 * 0.2)));
+        loglike += mcmc_exp(-difficulty * ((a - 1) * (a - 1) / (2 * 0.2 * 0.2) + (y - 0.5) * (y - 0.5) / (2 * 0.5 * 0.5)));
+        loglike += mcmc_exp(-difficulty * ((a + y) * (a + y) / (2 * 1) + (a - y - 2) * (a - y - 2) / (2 * 0.2 * 0.2)));
+        loglike += mcmc_exp(-difficulty * ((a + y) * (a + y) / (2 * 1) + (a - y + 2) * (a - y + 2) / (2 * 0.1)));
+        return mcmc_log(loglike);
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void toy_eval_kernel(const double* __restrict__ x, double* __restrict__ ll,
+                                                       long long n, double difficulty) {
+    constexpr int DIM = KIND == TOY_MYLIKE1 ? 3 : 2;
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    double v[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) v[k] = x[(long long)k * n + c];
+    ll[c] = toy_loglike<KIND>(v, difficulty);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void toy_run_kernel(double* __restrict__ x, double* __restrict__ stepsizes,
+                                                      const uint64_t* __restrict__ ids, long long n,
+                                                      double difficulty, const double* __restrict__ betas,
+                                                      int nSamples, int nBurnin, int nAdjust, int thinning,
+                                                      double* __restrict__ recLL, double* __restrict__ recS,
+                                                      int* __restrict__ nAcceptOut) {
+    constexpr int DIM = KIND == TOY_MYLIKE1 ? 3 : 2;
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    Pcg32 rnd;
+    pcg32_seed(rnd.state, rnd.inc, 0, ids[c]);                       /* rnd(0, chainid), mcmc.h:999 */
+    double cur[3] = {0, 0, 0}, prop[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) cur[k] = x[(long long)k * n + c];
+    double ll = toy_loglike<KIND>(cur, difficulty);
+    double sf = stepsizes[c];
+    int nAccept = 0, slot = 0;
+    for (int i = 0; i < nSamples + nAdjust; ++i) {                   /* mcmc.h:1023 */
+        const double beta = betas[i];
+        if (i == nAdjust) nAccept = 0;                               /* mcmc.h:1032 */
+        if (i >= nBurnin && (i % thinning) == 0) {                   /* mcmc.h:1037-1062 */
+            double l = 0;
+            l += ll;
+            if (recLL) recLL[(long long)slot * n + c] = 0.0 + beta * l;
+            if (recS) {
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) recS[((long long)slot * DIM + k) * n + c] = cur[k];
+            }
+            ++slot;
+        }
+        int reps = 1;
+        if (i < nAdjust) { nAccept = 0; reps = 20; }                 /* mcmc.h:1090-1105 */
+        for (int j = 0; j < reps; ++j) {
+            if (j == 0) (void)rnd.next_float();                      /* step_random_subspace, mcmc.h:498 */
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+                if constexpr (KIND == TOY_MYLIKE1) {
+                    prop[k] = cur[k] + 10 * sf * ((double)rnd.next_float() - 0.5);            /* test.h:50 */
+                } else {
+                    prop[k] = cur[k] + sf * ((double)rnd.next_float() - 0.5);                 /* test.h:105 */
+                    prop[k] = bound_reflect(prop[k], -5.0, 5.0);
+                }
+            }
+            const double llp = toy_loglike<KIND>(prop, difficulty);
+            double delta = 0;
+            delta += -ll + llp;
+            delta += 0.0;
+            delta *= beta;
+            if ((double)rnd.next_float() < 1.0 * mcmc_exp(delta)) {  /* mcmc.h:776 */
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) cur[k] = prop[k];
+                ll = llp;
+                ++nAccept;
+            }
+        }
+        if (i < nAdjust) sf *= rate2corr((double)nAccept / 20);      /* mcmc.h:1107-1114 */
+    }
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) x[(long long)k * n + c] = cur[k];
+    stepsizes[c] = sf;
+    nAcceptOut[c] = nAccept;
+}

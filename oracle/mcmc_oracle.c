@@ -632,7 +632,7 @@ static int toy_run(int dimx, toy_eval_fn ev, toy_prop_fn pr, const void* ud, dou
             double delta = 0; delta += -ll + llp;
             delta += (log(1.0) - log(1.0));
             delta *= beta;
-            if ((double)orc_pcg32_next_float(&rng) < 1.0 * exp(delta)) {
+            if ((double)orc_pcg32_next_float(&rng) < 1.0 * mcmc_exp(delta)) {
                 memcpy(x, xp, sizeof(double) * dimx); ll = llp; ++nAccept;
             }
         }
@@ -668,11 +668,12 @@ static double fourg_eval(const double* p, const void* ud) {
     double difficulty = *(const double*)ud;
     double x = p[0], y = p[1];
     double loglike;
-    loglike  = exp(-difficulty * ((x + 0.5) * (x + 0.5) / (2 * 0.5 * 0.5) + (y + 1) * (y + 1) / (2 * 0.2 * 0.2)));
-    loglike += exp(-difficulty * ((x - 1) * (x - 1) / (2 * 0.2 * 0.2) + (y - 0.5) * (y - 0.5) / (2 * 0.5 * 0.5)));
-    loglike += exp(-difficulty * ((x + y) * (x + y) / (2 * 1) + (x - y - 2) * (x - y - 2) / (2 * 0.2 * 0.2)));
-    loglike += exp(-difficulty * ((x + y) * (x + y) / (2 * 1) + (x - y + 2) * (x - y + 2) / (2 * 0.1)));
-    return log(loglike);
+    /* std::exp / std::log -> include/mcmc_detmath.h (<= 1 ulp from glibc), as in the HIP path */
+    loglike  = mcmc_exp(-difficulty * ((x + 0.5) * (x + 0.5) / (2 * 0.5 * 0.5) + (y + 1) * (y + 1) / (2 * 0.2 * 0.2)));
+    loglike += mcmc_exp(-difficulty * ((x - 1) * (x - 1) / (2 * 0.2 * 0.2) + (y - 0.5) * (y - 0.5) / (2 * 0.5 * 0.5)));
+    loglike += mcmc_exp(-difficulty * ((x + y) * (x + y) / (2 * 1) + (x - y - 2) * (x - y - 2) / (2 * 0.2 * 0.2)));
+    loglike += mcmc_exp(-difficulty * ((x + y) * (x + y) / (2 * 1) + (x - y + 2) * (x - y + 2) / (2 * 0.1)));
+    return mcmc_log(loglike);
 }
 static void fourg_prop(orc_pcg32* r, const double* x, double sf, double* xp, const void* ud) {
     (void)ud;
@@ -692,3 +693,7 @@ int orc_fourgauss_run(double difficulty, double T, int chain_id, const double* x
 /* mcmc_detmath.h entry points, exported so that tests can compare them with libm */
 double orc_det_cos(double x) { return mcmc_cos(x); }
 double orc_det_exp(double x) { return mcmc_exp(x); }
+double orc_det_log(double x) { return mcmc_log(x); }
+/* toy log-likelihoods alone, for batched-evaluation checks */
+double orc_mylike1_eval(const double* x) { return mylike1_eval(x, NULL); }
+double orc_fourgauss_eval(double difficulty, const double* x) { return fourg_eval(x, &difficulty); }

@@ -174,6 +174,9 @@ int orc_fourgauss_run(double difficulty, double T, int chain_id, const double* x
 /* include/mcmc_detmath.h, exported for tests */
 double orc_det_cos(double x);
 double orc_det_exp(double x);
+double orc_det_log(double x);
+double orc_mylike1_eval(const double* x);
+double orc_fourgauss_eval(double difficulty, const double* x);
 
 #ifdef __cplusplus
 }

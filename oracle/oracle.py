@@ -126,6 +126,12 @@ def lib():
     L.orc_det_cos.restype = C.c_double
     L.orc_det_exp.argtypes = [C.c_double]
     L.orc_det_exp.restype = C.c_double
+    L.orc_det_log.argtypes = [C.c_double]
+    L.orc_det_log.restype = C.c_double
+    L.orc_mylike1_eval.argtypes = [dp]
+    L.orc_mylike1_eval.restype = C.c_double
+    L.orc_fourgauss_eval.argtypes = [C.c_double, dp]
+    L.orc_fourgauss_eval.restype = C.c_double
     _lib = L
     return L
 

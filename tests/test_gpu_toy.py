@@ -1,0 +1,56 @@
+"""GPU parity of the toy targets of test.h (BASELINE configs[0]): MyLike1 under the CLI run
+of test.cpp:27-40 and FourGaussians under TempTarget, bit-exact against the oracle."""
+import numpy as np
+import pytest
+
+from mcmc_amd import hip as H
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mylike1_cli_config_bitexact():
+    """test.cpp:36-38: MyState, chain id 0, run(100000, 10, 500, 5)."""
+    r = H.toy_run("mylike1", [[1.0, 1.0, 1.0]], 100000, 10, 500, 5, first_chain_id=0)
+    ll, s, sf, nacc = O.mylike1_run(0, 100000, 10, 500, 5)
+    assert np.array_equal(r["loglikes"][0], ll) and np.array_equal(r["samples"][0], s)
+    assert r["stepsizes"][0] == sf and r["n_accept"][0] == nacc
+    post = r["samples"][0][200:]
+    assert np.all(np.abs(post.mean(axis=0)) < 0.05) and np.all(np.abs(post.var(axis=0) - 0.5) < 0.05)
+
+
+def test_mylike1_many_chains_and_ids():
+    n = 300
+    r = H.toy_run("mylike1", np.ones((n, 3)), 400, 0, 20, 4, first_chain_id=1)
+    for c in (0, 63, 64, 299):
+        ll, s, sf, nacc = O.mylike1_run(c + 1, 400, 0, 20, 4)
+        assert np.array_equal(r["loglikes"][c], ll) and np.array_equal(r["samples"][c], s)
+        assert r["stepsizes"][c] == sf and r["n_accept"][c] == nacc
+
+
+@pytest.mark.parametrize("T", [1.0, 10.0])
+def test_four_gaussians_tempered_bitexact(T):
+    """notebooks/test2.ipynb: FourGaussians(6) under TempTarget(10) as the hot generator chain."""
+    x0 = np.array([[0.0, 0.0], [1.0, 0.5], [-4.9, 4.9]])
+    r = H.toy_run("fourgauss", x0, 3000, 5, 100, 10, difficulty=6.0, target="temp", T=T, chain_ids=[0, 5, 9])
+    for i, cid in enumerate([0, 5, 9]):
+        ll, s, sf, nacc = O.fourgauss_run(6.0, T, cid, x0[i], 3000, 5, 100, 10)
+        assert np.array_equal(r["loglikes"][i], ll) and np.array_equal(r["samples"][i], s)
+        assert r["stepsizes"][i] == sf and r["n_accept"][i] == nacc
+    assert np.all(np.abs(r["samples"]) <= 5.0)
+
+
+def test_toy_eval_and_errors():
+    rs = np.random.RandomState(3)
+    x = rs.uniform(-5, 5, (100, 2))
+    got = H.toy_eval("fourgauss", x, difficulty=6.0)
+    L = O.lib()
+    want = np.array([L.orc_fourgauss_eval(6.0, np.ascontiguousarray(v).ctypes.data_as(O.C.POINTER(O.C.c_double))) for v in x])
+    assert np.array_equal(got, want)
+    x3 = rs.uniform(-3, 3, (50, 3))
+    got = H.toy_eval("mylike1", x3)
+    want = np.array([L.orc_mylike1_eval(np.ascontiguousarray(v).ctypes.data_as(O.C.POINTER(O.C.c_double))) for v in x3])
+    assert np.array_equal(got, want)
+    with pytest.raises(H.McmcHipError):
+        H.toy_run("mylike1", np.ones((2, 3)), 10, 0, 0, 0)       # thinning 0
+    assert H.lib().mcmc_hip_toy_dim(7) < 0

@@ -70,6 +70,10 @@ def test_detmath_within_one_ulp_of_libm():
         assert _ulps(L.orc_det_cos(x), math.cos(x)) <= 1
     for x in np.concatenate([rs.uniform(-745, 5, 20000), [0.0, -1e-10, 1e-10, -0.3, 0.3, -744.5, 709.0]]):
         assert _ulps(L.orc_det_exp(x), math.exp(x)) <= 1
+    for x in np.concatenate([rs.uniform(1e-300, 10, 20000), 10.0 ** rs.uniform(-320, 300, 5000), 1 + rs.uniform(-1e-6, 1e-6, 2000),
+                             [1.0, 0.5, 2.0, 5e-324, 1.7976931348623157e308]]):
+        assert _ulps(L.orc_det_log(x), math.log(x)) <= 1
+    assert L.orc_det_log(0.0) == -math.inf and math.isnan(L.orc_det_log(-1.0)) and L.orc_det_log(math.inf) == math.inf
     assert L.orc_det_exp(-1e4) == 0.0 and L.orc_det_exp(1e4) == math.inf
     assert math.isnan(L.orc_det_exp(math.nan)) and math.isnan(L.orc_det_cos(math.inf))
 
