@@ -184,17 +184,20 @@ int mcmc_hip_pair_count(mcmc_hip_ctx* ctx, double* pairs_out, int32_t reset);
  * FourGaussians(difficulty), each as the single likelihood of a State, under
  * MetropolisChain::run (mcmc.h:1005-1138) with Target / TempTarget / CoolingTarget.  One chain
  * per lane, the whole run in one launch; chain c draws pcg32(0, chain_ids[c]) (NULL:
- * first_chain_id + c).  x [n][dim] and stepsizes [n] are read and overwritten with the end
- * state; loglikes_out [n][n_saved], samples_out [n][n_saved][dim] (position / pos) and
- * n_accept_out [n] may be NULL. */
+ * first_chain_id + c).  x [n][dim] (position / pos) and stepsizes [n] are read and overwritten
+ * with the end state.  A saved point and the running mean (mcmc.h:1002,1064-1065,1133-1134)
+ * hold ALL coords of the likelihood, n_out = dim + 1 for MyLike1 (its coordinate "max",
+ * test.h:37) and dim for FourGaussians: loglikes_out [n][n_saved], samples_out
+ * [n][n_saved][n_out], mean_out [n][n_out] and n_accept_out [n] may each be NULL. */
 enum mcmc_toy_kind { MCMC_TOY_MYLIKE1 = 0, MCMC_TOY_FOURGAUSS = 1 };
 int mcmc_hip_toy_dim(int32_t kind);                                   /* 3, 2 */
+int mcmc_hip_toy_n_out(int32_t kind);                                 /* 4, 2 */
 int mcmc_hip_toy_eval(int device, int32_t kind, double difficulty, int64_t n, const double* x, double* ll_out);
 int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target_kind, double target_T,
                      double target_slope, double target_Tinit, int64_t n_chains, const uint64_t* chain_ids,
                      uint64_t first_chain_id, double* x, double* stepsizes, int32_t n_samples,
                      int32_t n_burnin, int32_t n_adjust, int32_t thinning, double* loglikes_out,
-                     double* samples_out, int32_t* n_accept_out);
+                     double* samples_out, double* mean_out, int32_t* n_accept_out);
 
 /* Profiling aid: shader cycles summed over all waves per phase of the MH step since the last
  * reset, out[16] in the order propose, eval set-up, lag chunks, lag tail, day loop,

@@ -820,9 +820,15 @@ int mcmc_hip_pair_count(mcmc_hip_ctx* c, double* pairs_out, int32_t reset) {
 
 /* ------------------------------------------------------------------ toy targets ---- */
 static int toy_dim(int kind) { return kind == MCMC_TOY_MYLIKE1 ? 3 : kind == MCMC_TOY_FOURGAUSS ? 2 : -1; }
+static int toy_n_out(int kind) { return kind == MCMC_TOY_MYLIKE1 ? 4 : kind == MCMC_TOY_FOURGAUSS ? 2 : -1; }
 
 int mcmc_hip_toy_dim(int32_t kind) {
     const int d = toy_dim(kind);
+    return d > 0 ? d : fail(MCMC_HIP_EINVAL, "unknown toy target %d", kind);
+}
+
+int mcmc_hip_toy_n_out(int32_t kind) {
+    const int d = toy_n_out(kind);
     return d > 0 ? d : fail(MCMC_HIP_EINVAL, "unknown toy target %d", kind);
 }
 
@@ -858,8 +864,8 @@ int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target
                      double target_slope, double target_Tinit, int64_t n, const uint64_t* chain_ids,
                      uint64_t first_chain_id, double* x, double* stepsizes, int32_t nSamples, int32_t nBurnin,
                      int32_t nAdjust, int32_t thinning, double* loglikes_out, double* samples_out,
-                     int32_t* n_accept_out) {
-    const int dim = toy_dim(kind);
+                     double* mean_out, int32_t* n_accept_out) {
+    const int dim = toy_dim(kind), nOut = toy_n_out(kind);
     if (dim < 0 || n < 1 || !x || !stepsizes) return fail(MCMC_HIP_EINVAL, "toy_run: bad arguments");
     if (nSamples < 0 || nBurnin < 0 || nAdjust < 0 || thinning < 1)
         return fail(MCMC_HIP_EINVAL, "toy_run: need n_samples,n_burnin,n_adjust >= 0 and thinning >= 1");
@@ -878,7 +884,7 @@ int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target
         ids[c] = chain_ids ? chain_ids[c] : first_chain_id + (uint64_t)c;
         for (int k = 0; k < dim; ++k) soa[(size_t)k * n + c] = x[c * dim + k];
     }
-    DevBuf<double> dx, dss, dbeta, dll, dsamp;
+    DevBuf<double> dx, dss, dbeta, dll, dsamp, dmean;
     DevBuf<uint64_t> dids;
     DevBuf<int> dacc;
     if (int r = dx.alloc(soa.size())) return r;
@@ -887,7 +893,8 @@ int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target
     if (int r = dids.alloc(n)) return r;
     if (int r = dacc.alloc(n)) return r;
     if (loglikes_out && nSaved > 0) { if (int r = dll.alloc((size_t)nSaved * n)) return r; }
-    if (samples_out && nSaved > 0) { if (int r = dsamp.alloc((size_t)nSaved * dim * n)) return r; }
+    if (samples_out && nSaved > 0) { if (int r = dsamp.alloc((size_t)nSaved * nOut * n)) return r; }
+    if (mean_out) { if (int r = dmean.alloc((size_t)nOut * n)) return r; }
     HIP_TRY(hipMemcpy(dx.p, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dss.p, stepsizes, n * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dbeta.p, betas.data(), betas.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -895,10 +902,10 @@ int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target
     const unsigned grid = (unsigned)((n + 255) / 256);
     if (kind == MCMC_TOY_MYLIKE1)
         hipLaunchKernelGGL(toy_run_kernel<TOY_MYLIKE1>, dim3(grid), dim3(256), 0, 0, dx.p, dss.p, (const uint64_t*)dids.p, (long long)n,
-                           difficulty, (const double*)dbeta.p, nSamples, nBurnin, nAdjust, thinning, dll.p, dsamp.p, dacc.p);
+                           difficulty, (const double*)dbeta.p, nSamples, nBurnin, nAdjust, thinning, dll.p, dsamp.p, dmean.p, dacc.p);
     else
         hipLaunchKernelGGL(toy_run_kernel<TOY_FOURGAUSS>, dim3(grid), dim3(256), 0, 0, dx.p, dss.p, (const uint64_t*)dids.p, (long long)n,
-                           difficulty, (const double*)dbeta.p, nSamples, nBurnin, nAdjust, thinning, dll.p, dsamp.p, dacc.p);
+                           difficulty, (const double*)dbeta.p, nSamples, nBurnin, nAdjust, thinning, dll.p, dsamp.p, dmean.p, dacc.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(soa.data(), dx.p, soa.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -913,11 +920,17 @@ int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target
             for (int s = 0; s < nSaved; ++s) loglikes_out[c * nSaved + s] = h[(size_t)s * n + c];
     }
     if (dsamp.p) {
-        std::vector<double> h((size_t)nSaved * dim * n);
+        std::vector<double> h((size_t)nSaved * nOut * n);
         HIP_TRY(hipMemcpy(h.data(), dsamp.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
         for (int64_t c = 0; c < n; ++c)
             for (int s = 0; s < nSaved; ++s)
-                for (int k = 0; k < dim; ++k) samples_out[((size_t)c * nSaved + s) * dim + k] = h[((size_t)s * dim + k) * n + c];
+                for (int k = 0; k < nOut; ++k) samples_out[((size_t)c * nSaved + s) * nOut + k] = h[((size_t)s * nOut + k) * n + c];
+    }
+    if (dmean.p) {
+        std::vector<double> h((size_t)nOut * n);
+        HIP_TRY(hipMemcpy(h.data(), dmean.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t c = 0; c < n; ++c)
+            for (int k = 0; k < nOut; ++k) mean_out[(size_t)c * nOut + k] = h[(size_t)k * n + c];
     }
     return 0;
 }

@@ -1110,8 +1110,9 @@ __global__ __launch_bounds__(256) void toy_run_kernel(double* __restrict__ x, do
                                                       double difficulty, const double* __restrict__ betas,
                                                       int nSamples, int nBurnin, int nAdjust, int thinning,
                                                       double* __restrict__ recLL, double* __restrict__ recS,
-                                                      int* __restrict__ nAcceptOut) {
+                                                      double* __restrict__ meanOut, int* __restrict__ nAcceptOut) {
     constexpr int DIM = KIND == TOY_MYLIKE1 ? 3 : 2;
+    constexpr int NOUT = KIND == TOY_MYLIKE1 ? 4 : 2;                /* + the coordinate "max", test.h:37 */
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     Pcg32 rnd;
@@ -1122,18 +1123,27 @@ __global__ __launch_bounds__(256) void toy_run_kernel(double* __restrict__ x, do
     double ll = toy_loglike<KIND>(cur, difficulty);
     double sf = stepsizes[c];
     int nAccept = 0, slot = 0;
+    /* mean = deep copy of the evaluated initial state (mcmc.h:1002) */
+    double mean[4] = {cur[0], cur[1], cur[2], fmax(fmax(cur[0], cur[1]), cur[2])};
     for (int i = 0; i < nSamples + nAdjust; ++i) {                   /* mcmc.h:1023 */
         const double beta = betas[i];
         if (i == nAdjust) nAccept = 0;                               /* mcmc.h:1032 */
+        const double curMax = fmax(fmax(cur[0], cur[1]), cur[2]);    /* test.h:37 */
         if (i >= nBurnin && (i % thinning) == 0) {                   /* mcmc.h:1037-1062 */
             double l = 0;
             l += ll;
             if (recLL) recLL[(long long)slot * n + c] = 0.0 + beta * l;
             if (recS) {
 #pragma unroll
-                for (int k = 0; k < DIM; ++k) recS[((long long)slot * DIM + k) * n + c] = cur[k];
+                for (int k = 0; k < DIM; ++k) recS[((long long)slot * NOUT + k) * n + c] = cur[k];
+                if constexpr (NOUT > DIM) recS[((long long)slot * NOUT + DIM) * n + c] = curMax;
             }
             ++slot;
+        }
+        if (i > nBurnin && meanOut) {                                /* mcmc.h:1064-1065 */
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) mean[k] += cur[k];
+            mean[3] += curMax;
         }
         int reps = 1;
         if (i < nAdjust) { nAccept = 0; reps = 20; }                 /* mcmc.h:1090-1105 */
@@ -1166,4 +1176,11 @@ __global__ __launch_bounds__(256) void toy_run_kernel(double* __restrict__ x, do
     for (int k = 0; k < DIM; ++k) x[(long long)k * n + c] = cur[k];
     stepsizes[c] = sf;
     nAcceptOut[c] = nAccept;
+    if (meanOut) {                                                   /* mcmc.h:1133-1134 */
+        const int cnt = nAdjust + nSamples - nBurnin;
+        const double f = cnt != 0 ? 1.0 / (double)cnt : 1.0;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) meanOut[(long long)k * n + c] = mean[k] * f;
+        if constexpr (NOUT > DIM) meanOut[(long long)DIM * n + c] = mean[3] * f;
+    }
 }

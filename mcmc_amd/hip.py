@@ -28,7 +28,7 @@ SYMBOLS = [
     "mcmc_hip_get_accept_counts", "mcmc_hip_get_rng_state", "mcmc_hip_get_loglikes",
     "mcmc_hip_get_samples", "mcmc_hip_get_sample_all", "mcmc_hip_get_mean", "mcmc_hip_eval",
     "mcmc_hip_derive", "mcmc_hip_diagnostics", "mcmc_hip_last_timing", "mcmc_hip_pair_count",
-    "mcmc_hip_debug_phase_cycles", "mcmc_hip_toy_dim", "mcmc_hip_toy_eval", "mcmc_hip_toy_run",
+    "mcmc_hip_debug_phase_cycles", "mcmc_hip_toy_dim", "mcmc_hip_toy_n_out", "mcmc_hip_toy_eval", "mcmc_hip_toy_run",
 ]
 
 
@@ -98,10 +98,11 @@ def lib():
     L.mcmc_hip_pair_count.argtypes = [vp, dp, C.c_int32]
     L.mcmc_hip_debug_phase_cycles.argtypes = [vp, dp, C.c_int32]
     L.mcmc_hip_toy_dim.argtypes = [C.c_int32]
+    L.mcmc_hip_toy_n_out.argtypes = [C.c_int32]
     L.mcmc_hip_toy_eval.argtypes = [C.c_int, C.c_int32, C.c_double, C.c_int64, dp, dp]
     L.mcmc_hip_toy_run.argtypes = [C.c_int, C.c_int32, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_double,
                                    C.c_int64, C.POINTER(C.c_uint64), C.c_uint64, dp, dp, C.c_int32, C.c_int32,
-                                   C.c_int32, C.c_int32, dp, dp, C.POINTER(C.c_int32)]
+                                   C.c_int32, C.c_int32, dp, dp, dp, C.POINTER(C.c_int32)]
     _lib = L
     return L
 
@@ -148,7 +149,8 @@ def toy_eval(kind, x, difficulty=1.0, device=0):
 def toy_run(kind, x0, n_samples, n_burnin, n_adjust, thinning, difficulty=1.0, target="plain", T=1.0, slope=0.0,
             Tinit=1.0, stepsizes=1.0, chain_ids=None, first_chain_id=0, device=0):
     """MetropolisChain::run for n toy chains on the GPU (test.cpp:27-40 is kind='mylike1',
-    one chain, id 0, x0 = (1,1,1), run(100000, 10, 500, 5)).  Returns a dict."""
+    one chain, id 0, x0 = (1,1,1), run(100000, 10, 500, 5)).  Returns a dict; `samples` and
+    `mean` have n_out columns (MyLike1: position + its coordinate "max")."""
     L = lib()
     x = np.array(np.atleast_2d(x0), dtype=np.float64, order="C")
     n, dim = x.shape
@@ -156,14 +158,16 @@ def toy_run(kind, x0, n_samples, n_burnin, n_adjust, thinning, difficulty=1.0, t
     ss = np.array(np.broadcast_to(stepsizes, (n,)), dtype=np.float64)
     ns = L.mcmc_hip_n_saved(n_samples, n_burnin, n_adjust, thinning)
     ll = np.zeros((n, ns))
-    samples = np.zeros((n, ns, dim))
+    n_out = L.mcmc_hip_toy_n_out(TOY[kind])
+    samples = np.zeros((n, ns, n_out))
+    mean = np.zeros((n, n_out))
     acc = np.zeros(n, dtype=np.int32)
     ids = None if chain_ids is None else np.ascontiguousarray(chain_ids, dtype=np.uint64)
     _check(L.mcmc_hip_toy_run(device, TOY[kind], difficulty, _KIND[target], T, slope, Tinit, n,
                               ids.ctypes.data_as(C.POINTER(C.c_uint64)) if ids is not None else None,
                               first_chain_id, _dp(x), _dp(ss), n_samples, n_burnin, n_adjust, thinning,
-                              _dp(ll), _dp(samples), acc.ctypes.data_as(C.POINTER(C.c_int32))))
-    return dict(x=x, stepsizes=ss, loglikes=ll, samples=samples, n_accept=acc)
+                              _dp(ll), _dp(samples), _dp(mean), acc.ctypes.data_as(C.POINTER(C.c_int32))))
+    return dict(x=x, stepsizes=ss, loglikes=ll, samples=samples, mean=mean, n_accept=acc)
 
 
 class CovidSampler:

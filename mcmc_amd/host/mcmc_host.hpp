@@ -1,7 +1,7 @@
 /*
  * mcmc_host.hpp -- C++17 host side of the MI355X Metropolis-Hastings hot path.
  *
- * Mirrors, for the covid path, the interface of AndreasFinke/mcmc that a user program or
+ * Mirrors, for the Metropolis-Hastings path, the interface of AndreasFinke/mcmc that a user program or
  * the pybind11 module touches: SubspaceState / SmoothnessPrior / DiseaseData /
  * DiseaseParams / DiseaseSpread / State / Target / TempTarget / CoolingTarget /
  * MetropolisChain / ChainManager (mcmc.h:62-228, 241-700, 705-841, 984-1312, 1314-1655;
@@ -14,8 +14,9 @@
  * mcmc.h:1494-1508, 1534-1548).  There is no CPU fallback: without the library or a GPU
  * the calls report the C ABI's error.
  *
- * Only the State composition of the covid notebooks is supported:
- *     State = [ DiseaseSpread ]  or  [ DiseaseSpread, SmoothnessPrior("behavior", Ls, L) ].
+ * Supported State compositions: the covid notebooks' [ DiseaseSpread ] or
+ * [ DiseaseSpread, SmoothnessPrior("behavior", Ls, L) ], and the single toy likelihoods of
+ * test.h, [ MyLike1 ] (= MyState, the CLI run of test.cpp:27-40) and [ FourGaussians(d) ].
  * Everything is header-only and uses nothing but the C ABI, so a C++ program can use it
  * without Python; mcmc_amd/pymod/mcmc_module.cpp wraps it for Python.
  */
@@ -261,6 +262,42 @@ public:
     }
 };
 
+/* --------------------------------------------------------------- toy likelihoods ---- */
+/* test.h:14-136.  Both pass (names, 1, false) to a constructor whose order is
+ * (names, derivedOnShared, nDerived) (mcmc.h:75), i.e. derivedOnShared = true and
+ * nDerived = 0: MyLike1's coordinate "max" counts as a coordinate like "position". */
+class ToyLikelihood : public SubspaceState {
+public:
+    ToyLikelihood(std::vector<std::string>&& coordNames, int kind, Float difficulty)
+        : SubspaceState(std::move(coordNames), true, 0), toyKind(kind), difficulty(difficulty) {}
+    int toyKind;
+    Float difficulty;
+    size_t nSampled() const { return coords[0].size(); }                  /* what step() moves */
+    size_t nOut() const { size_t n = 0; for (auto& c : coords) n += c.size(); return n; }
+    std::vector<Float> pack() const { return coords[0]; }
+    /* coords that eval() sets besides loglike */
+    virtual void refresh_derived() {}
+    void unpack(const Float* x) { for (auto& v : coords[0]) v = *x++; refresh_derived(); }
+    virtual std::vector<Float> sampleInitialConditions(pcg32&) { return {}; }   /* mcmc.h:112-114 */
+};
+class MyLike1 : public ToyLikelihood {
+public:
+    MyLike1() : ToyLikelihood({"position", "max"}, MCMC_TOY_MYLIKE1, 1) { setCoords({{1, 1, 1}, {1}}); }   /* test.h:18-22 */
+    void refresh_derived() override { coords[1][0] = std::max(std::max(coords[0][0], coords[0][1]), coords[0][2]); } /* test.h:37 */
+    std::shared_ptr<SubspaceState> copy() const override { return std::make_shared<MyLike1>(*this); }
+};
+class FourGaussians : public ToyLikelihood {
+public:
+    FourGaussians(Float difficulty) : ToyLikelihood({"pos"}, MCMC_TOY_FOURGAUSS, difficulty) { setCoords({{0, 0}}); } /* test.h:73-77 */
+    std::vector<Float> sampleInitialConditions(pcg32& rnd) override {    /* test.h:116-123 */
+        std::vector<Float> ret = {-5 + 10 * rnd.nextDouble()};
+        ret.push_back(-5 + 10 * rnd.nextDouble());
+        unpack(ret.data());
+        return ret;
+    }
+    std::shared_ptr<SubspaceState> copy() const override { return std::make_shared<FourGaussians>(*this); }
+};
+
 /* ---------------------------------------------------------------- device engine ---- */
 enum class TargetKind { Plain = MCMC_TARGET_PLAIN, Temp = MCMC_TARGET_TEMP, Cooling = MCMC_TARGET_COOLING };
 struct TargetSpec { TargetKind kind = TargetKind::Plain; Float T = 1, slope = 0, Tinit = 1; };
@@ -315,8 +352,113 @@ public:
     int dim = 0, size = 0;
 };
 
+/* What one batched device run recorded, chain-major.  A saved point / mean row has nOut
+ * columns: the sampled coordinates (covid) or all coords of the toy likelihood. */
+struct BatchResults {
+    size_t n = 0, dim = 0, nOut = 0;
+    int nSaved = 0;
+    std::vector<Float> lls, params, mean, fll, fss;      /* [n][nSaved] [n][dim] [n][nOut] [n][2] [n] */
+    std::vector<int32_t> acc;
+    std::vector<std::vector<Float>> saved;               /* [nSaved] of [n][nOut] */
+    std::vector<Float> diagnostics;                      /* mcmc_hip_diagnostics (covid) */
+};
+
+/* The device work behind one supported State composition. */
+class Backend {
+public:
+    virtual ~Backend() {}
+    virtual size_t dim() const = 0;
+    virtual size_t n_out() const = 0;
+    virtual size_t curve_len() const { return 0; }
+    /* ll [n][2]: (likelihood, prior) */
+    virtual void eval(size_t n, const Float* x, Float* ll) = 0;
+    /* derived output curves of the covid model, [n][9][curve_len] */
+    virtual void derive(size_t, const Float*, Float*) { throw std::logic_error("derive: not a covid state"); }
+    /* MetropolisChain::run for n chains with ids firstId.. */
+    virtual void run(BatchResults& R, size_t n, const Float* x, const Float* ss, uint64_t firstId, int nSamples,
+                     int nBurnin, int nAdjust, int thinning) = 0;
+};
+
+class CovidBackend : public Backend {
+public:
+    CovidBackend(const DiseaseSpread& ds, const SmoothnessPrior* prior, const TargetSpec& t) : eng(ds, prior, t) {}
+    size_t dim() const override { return (size_t)eng.dim; }
+    size_t n_out() const override { return (size_t)eng.dim; }
+    size_t curve_len() const override { return (size_t)eng.size; }
+    void eval(size_t n, const Float* x, Float* ll) override {
+        hip_check(mcmc_hip_eval(eng.ctx, (int64_t)n, x, ll), "mcmc_hip_eval");
+    }
+    void derive(size_t n, const Float* x, Float* curves) override {
+        hip_check(mcmc_hip_derive(eng.ctx, (int64_t)n, x, curves), "mcmc_hip_derive");
+    }
+    void run(BatchResults& R, size_t n, const Float* x, const Float* ss, uint64_t firstId, int nSamples, int nBurnin,
+             int nAdjust, int thinning) override {
+        const size_t d = dim();
+        hip_check(mcmc_hip_set_chains(eng.ctx, (int64_t)n, x, ss, nullptr, firstId), "mcmc_hip_set_chains");
+        /* the parameter samples are what the reference keeps as `ics` of every saved point
+         * (mcmc.h:1042-1045), whatever recordSamples says */
+        hip_check(mcmc_hip_run(eng.ctx, nSamples, nBurnin, nAdjust, thinning, 1, 1), "mcmc_hip_run");
+        const int nSaved = mcmc_hip_n_saved(nSamples, nBurnin, nAdjust, thinning);
+        R = BatchResults{};
+        R.lls.assign(n * (size_t)std::max(nSaved, 1), 0); R.params.assign(n * d, 0); R.mean.assign(n * d, 0);
+        R.fll.assign(n * 2, 0); R.fss.assign(n, 0); R.acc.assign(n, 0);
+        if (nSaved > 0) hip_check(mcmc_hip_get_loglikes(eng.ctx, R.lls.data()), "mcmc_hip_get_loglikes");
+        hip_check(mcmc_hip_get_params(eng.ctx, R.params.data()), "mcmc_hip_get_params");
+        hip_check(mcmc_hip_get_mean(eng.ctx, R.mean.data()), "mcmc_hip_get_mean");
+        hip_check(mcmc_hip_get_loglike(eng.ctx, R.fll.data()), "mcmc_hip_get_loglike");
+        hip_check(mcmc_hip_get_stepsizes(eng.ctx, R.fss.data()), "mcmc_hip_get_stepsizes");
+        hip_check(mcmc_hip_get_accept_counts(eng.ctx, R.acc.data()), "mcmc_hip_get_accept_counts");
+        R.saved.assign(nSaved, std::vector<Float>(n * d));
+        for (int s = 0; s < nSaved; ++s) hip_check(mcmc_hip_get_sample_all(eng.ctx, s, R.saved[s].data()), "mcmc_hip_get_sample_all");
+        R.diagnostics.assign(4 + 2 * d, 0);
+        hip_check(mcmc_hip_diagnostics(eng.ctx, R.diagnostics.data()), "mcmc_hip_diagnostics");
+        R.n = n; R.dim = d; R.nOut = d; R.nSaved = nSaved;
+    }
+    Engine eng;
+};
+
+class ToyBackend : public Backend {
+public:
+    ToyBackend(const ToyLikelihood& t, const TargetSpec& spec, int device = 0)
+        : kind(t.toyKind), difficulty(t.difficulty), spec(spec), device(device) {
+        d = mcmc_hip_toy_dim(kind); no = mcmc_hip_toy_n_out(kind);
+        if (d < 0 || no < 0) throw HipError(d, std::string("ToyBackend: ") + mcmc_hip_last_error());
+    }
+    size_t dim() const override { return (size_t)d; }
+    size_t n_out() const override { return (size_t)no; }
+    void eval(size_t n, const Float* x, Float* ll) override {
+        std::vector<Float> l(n);
+        hip_check(mcmc_hip_toy_eval(device, kind, difficulty, (int64_t)n, x, l.data()), "mcmc_hip_toy_eval");
+        for (size_t i = 0; i < n; ++i) { ll[2 * i] = l[i]; ll[2 * i + 1] = 0; }
+    }
+    void run(BatchResults& R, size_t n, const Float* x, const Float* ss, uint64_t firstId, int nSamples, int nBurnin,
+             int nAdjust, int thinning) override {
+        const int nSaved = mcmc_hip_n_saved(nSamples, nBurnin, nAdjust, thinning);
+        R = BatchResults{};
+        R.params.assign(x, x + n * d);
+        R.fss.assign(ss, ss + n);
+        R.lls.assign(n * (size_t)std::max(nSaved, 1), 0); R.mean.assign(n * no, 0); R.acc.assign(n, 0);
+        std::vector<Float> samples(n * (size_t)std::max(nSaved, 1) * no);
+        hip_check(mcmc_hip_toy_run(device, kind, difficulty, (int32_t)spec.kind, spec.T, spec.slope, spec.Tinit, (int64_t)n,
+                                   nullptr, firstId, R.params.data(), R.fss.data(), nSamples, nBurnin, nAdjust, thinning,
+                                   R.lls.data(), samples.data(), R.mean.data(), R.acc.data()), "mcmc_hip_toy_run");
+        R.saved.assign(nSaved, std::vector<Float>(n * no));
+        for (int s = 0; s < nSaved; ++s)
+            for (size_t c = 0; c < n; ++c)
+                std::copy(samples.begin() + (c * nSaved + s) * no, samples.begin() + (c * nSaved + s + 1) * no,
+                          R.saved[s].begin() + c * no);
+        R.fll.assign(n * 2, 0);
+        eval(n, R.params.data(), R.fll.data());
+        R.n = n; R.dim = d; R.nOut = no; R.nSaved = nSaved;
+    }
+private:
+    int kind; Float difficulty; TargetSpec spec; int device; int d = 0, no = 0;
+};
+
 /* ------------------------------------------------------------------------- State ---- */
-/* mcmc.h:241-700, restricted to the covid composition */
+/* mcmc.h:241-700, restricted to the compositions the device path runs:
+ *     [ DiseaseSpread ],  [ DiseaseSpread, SmoothnessPrior("behavior", Ls, L) ],
+ *     [ MyLike1 ],  [ FourGaussians(difficulty) ] */
 class State {
 public:
     std::vector<std::shared_ptr<SubspaceState>> state;
@@ -327,6 +469,7 @@ public:
     bool isEvaluated = false;
     int sharedDependencyMaxDepth = 10;
 
+    virtual ~State() {}
     void add(const std::shared_ptr<SubspaceState>& s) { state.push_back(s); dim += s->dim; }
 
     DiseaseSpread* disease() const {
@@ -335,12 +478,40 @@ public:
     SmoothnessPrior* prior() const {
         return state.size() < 2 ? nullptr : dynamic_cast<SmoothnessPrior*>(state[1].get());
     }
+    ToyLikelihood* toy() const {
+        return state.size() != 1 ? nullptr : dynamic_cast<ToyLikelihood*>(state[0].get());
+    }
     bool supported(std::string* why = nullptr) const {
         auto fail = [&](const char* m) { if (why) *why = m; return false; };
-        if (state.empty() || !disease()) return fail("the first likelihood must be a DiseaseSpread");
+        if (toy()) return true;
+        if (state.empty() || !disease())
+            return fail("the first likelihood must be a DiseaseSpread (or the state a single MyLike1 / FourGaussians)");
         if (state.size() > 2) return fail("at most [DiseaseSpread, SmoothnessPrior] is supported on the GPU path");
         if (state.size() == 2 && (!prior() || prior()->functionName != "behavior"))
             return fail("the second likelihood must be SmoothnessPrior(\"behavior\", ...)");
+        return true;
+    }
+    /* the device work for this composition under a target */
+    std::unique_ptr<Backend> backend(const TargetSpec& t) const {
+        std::string why;
+        if (!supported(&why)) throw std::runtime_error("State: " + why);
+        if (ToyLikelihood* tl = toy()) return std::make_unique<ToyBackend>(*tl, t);
+        return std::make_unique<CovidBackend>(*disease(), prior(), t);
+    }
+    /* the coordinates a chain moves, in the C ABI's order */
+    std::vector<Float> packed() const { return toy() ? toy()->pack() : disease() ? disease()->pack() : std::vector<Float>{}; }
+    void set_packed(const Float* x) { if (toy()) toy()->unpack(x); else if (disease()) disease()->unpack(x); }
+    /* columns [off, off+len) of a saved point / mean row that hold coordinate `name` */
+    bool out_range(const std::string& name, size_t& off, size_t& len) const {
+        if (state.empty()) return false;
+        const SubspaceState& s = *state[0];
+        const size_t nc = toy() ? s.getCoords().size() : 5;
+        const std::map<std::string, size_t> names = s.get_names();
+        const auto it = names.find(name);
+        if (it == names.end() || it->second >= nc) return false;
+        off = 0;
+        for (size_t k = 0; k < it->second; ++k) off += s.getCoords()[k].size();
+        len = s.getCoords()[it->second].size();
         return true;
     }
 
@@ -358,18 +529,19 @@ public:
 
     /* State::eval (mcmc.h:385-393) on the device: log-likelihoods and the derived curves */
     void eval() {
-        std::string why;
-        if (!supported(&why)) throw std::runtime_error("State::eval: " + why);
-        DiseaseSpread* ds = disease();
-        Engine eng(*ds, prior(), TargetSpec{});
-        const std::vector<Float> x = ds->pack();
+        std::unique_ptr<Backend> be = backend(TargetSpec{});
+        const std::vector<Float> x = packed();
         Float ll[2] = {0, 0};
-        hip_check(mcmc_hip_eval(eng.ctx, 1, x.data(), ll), "mcmc_hip_eval");
-        std::vector<Float> curves((size_t)9 * eng.size);
-        hip_check(mcmc_hip_derive(eng.ctx, 1, x.data(), curves.data()), "mcmc_hip_derive");
-        ds->loglike = ll[0];
-        ds->set_derived(curves.data());
-        if (prior()) prior()->loglike = ll[1];
+        be->eval(1, x.data(), ll);
+        state[0]->loglike = ll[0];
+        if (DiseaseSpread* ds = disease()) {
+            std::vector<Float> curves((size_t)9 * be->curve_len());
+            be->derive(1, x.data(), curves.data());
+            ds->set_derived(curves.data());
+            if (prior()) prior()->loglike = ll[1];
+        } else {
+            toy()->refresh_derived();
+        }
         isEvaluated = true;
     }
 
@@ -401,20 +573,34 @@ public:
         for (auto& s : ret.state) s = s->copy();
         return std::make_shared<State>(ret);
     }
-    /* DiseaseSpread has no sampleInitialConditions (the base returns {}, mcmc.h:112-114): a
-     * state's initial conditions are its sampled coordinates */
+    /* mcmc.h:317-325.  Only FourGaussians draws something (test.h:116-123); the other
+     * likelihoods keep the base's empty answer (mcmc.h:112-114) and stay where they are. */
+    std::vector<std::vector<Float>> sampleInitialConditions(pcg32& rnd) {
+        if (ToyLikelihood* t = toy()) t->sampleInitialConditions(rnd);
+        isEvaluated = false;
+        eval();
+        return getInitialConditions();
+    }
+    /* DiseaseSpread and MyLike1 have no getInitialConditions (the base returns {},
+     * mcmc.h:116-118): here a state's initial conditions are the coordinates a chain moves */
     std::vector<std::vector<Float>> getInitialConditions() {
-        initialConditions = {disease() ? disease()->pack() : std::vector<Float>{}};
+        initialConditions = {packed()};
         for (size_t i = 1; i < state.size(); ++i) initialConditions.push_back({});
         return initialConditions;
     }
     void setInitialConditions(const std::vector<std::vector<Float>>& ics) {
         if (ics.size() != state.size()) throw std::invalid_argument("setInitialConditions: wrong number of likelihoods");
         initialConditions = ics;
-        if (disease() && ics[0].size() == disease()->nSampled()) disease()->unpack(ics[0].data());
+        if (ics[0].size() >= packed().size() && !ics[0].empty()) set_packed(ics[0].data());
         isEvaluated = false;
         eval();
     }
+};
+
+/* test.h:296-310 */
+class MyState : public State {
+public:
+    MyState() { state.push_back(std::make_shared<MyLike1>()); init(); }
 };
 
 /* ------------------------------------------------------------------------ Target ---- */
@@ -474,13 +660,33 @@ public:
 /* --------------------------------------------------------------- MetropolisChain ---- */
 /* What one chain recorded (MetropolisChain::loglikes / ics / mean, mcmc.h:1307-1310). */
 struct ChainRecord {
-    std::vector<Float> loglikes;                       /* [nSaved]                            */
-    std::vector<std::vector<Float>> ics;               /* [nSaved][dim] sampled coordinates   */
-    std::vector<Float> mean;                           /* [dim]                               */
-    std::vector<Float> finalParams;                    /* [dim]                               */
+    std::vector<Float> loglikes;                       /* [nSaved]                              */
+    std::vector<std::vector<Float>> ics;               /* [nSaved][nOut] rows of saved points   */
+    std::vector<Float> mean;                           /* [nOut]                                */
+    std::vector<Float> finalParams;                    /* [dim]                                 */
     Float finalLL[2] = {0, 0};
     Float stepsize = 1;
     int nAccept = 0;
+
+    /* chain `i` of a batched run */
+    void take(const BatchResults& R, size_t i) {
+        const size_t ns = (size_t)R.nSaved;
+        loglikes.assign(R.lls.begin() + i * ns, R.lls.begin() + (i + 1) * ns);
+        ics.clear();
+        for (size_t s = 0; s < ns; ++s) ics.emplace_back(R.saved[s].begin() + i * R.nOut, R.saved[s].begin() + (i + 1) * R.nOut);
+        mean.assign(R.mean.begin() + i * R.nOut, R.mean.begin() + (i + 1) * R.nOut);
+        finalParams.assign(R.params.begin() + i * R.dim, R.params.begin() + (i + 1) * R.dim);
+        finalLL[0] = R.fll[2 * i]; finalLL[1] = R.fll[2 * i + 1];
+        stepsize = R.fss[i];
+        nAccept = R.acc[i];
+    }
+    /* makes `st` the chain's end state */
+    void apply_to(State& st) const {
+        st.set_packed(finalParams.data());
+        st.state[0]->loglike = finalLL[0];
+        st.state[0]->stepsizeCorrectionFac = stepsize;
+        if (st.prior()) st.prior()->loglike = finalLL[1];
+    }
 };
 
 /* mcmc.h:984-1312.  run() drives the device for this one chain; a chain handed out by
@@ -503,18 +709,23 @@ public:
         std::string why;
         if (!target->state->supported(&why)) { std::cout << "MetropolisChain::run: " << why << ".\n"; return; }
         if (thinning < 1) { std::cout << "MetropolisChain::run: thinning must be at least 1.\n"; return; }
-        DiseaseSpread* ds = target->state->disease();
-        Engine eng(*ds, target->state->prior(), target->spec());
-        const std::vector<Float> x = ds->pack();
-        const Float ss = ds->stepsizeCorrectionFac;
-        const uint64_t cid = (uint64_t)id;
-        hip_check(mcmc_hip_set_chains(eng.ctx, 1, x.data(), &ss, &cid, 0), "mcmc_hip_set_chains");
+        State& st = *target->state;
+        std::unique_ptr<Backend> be = st.backend(target->spec());
+        const std::vector<Float> x = st.packed();
+        const Float ss = st.state[0]->stepsizeCorrectionFac;
         std::cout << "Starting to adjust and sample.\n";
-        hip_check(mcmc_hip_run(eng.ctx, nSamples, nBurnin, nAdjust, thinning, 1, computeMean ? 1 : 0), "mcmc_hip_run");
-        collect(eng, 0, mcmc_hip_n_saved(nSamples, nBurnin, nAdjust, thinning), true, computeMean, rec);
+        BatchResults R;
+        be->run(R, 1, x.data(), &ss, (uint64_t)id, nSamples, nBurnin, nAdjust, thinning);
+        rec.take(R, 0);
+        if (!computeMean) rec.mean.clear();
         haveSamples = recordSamples || writeSamplesToDisk;
-        apply_final_state(eng);
-        if (writeSamplesToDisk) write_samples(eng);
+        rec.apply_to(st);
+        if (st.disease()) {
+            std::vector<Float> curves((size_t)9 * be->curve_len());
+            be->derive(1, rec.finalParams.data(), curves.data());
+            st.disease()->set_derived(curves.data());
+        }
+        if (writeSamplesToDisk) write_samples(*be);
         std::cout << "\nThe final acceptance rate was " << (double)rec.nAccept / std::max(nBurnin + nSamples, 1)
                   << "." << std::endl;                                                        /* mcmc.h:1136 */
     }
@@ -539,56 +750,57 @@ public:
         if (evalstate && evalstate->supported()) evalState = evalstate;
         haveSamples = true;
         if (writeSamplesToDisk) {
-            State* st = evalState ? evalState.get() : target->state.get();
-            Engine eng(*st->disease(), st->prior(), target->spec());
-            write_samples(eng);
+            std::unique_ptr<Backend> be = eval_state()->backend(target->spec());
+            write_samples(*be);
         }
     }
 
     /* getters of the pybind surface (mcmc.h:1236-1301), as plain vectors */
     std::vector<Float> get_mean(const std::string& coordName) {
         if (!computeMean) std::cout << "Requested mean, but MetropolisChain::computeMean is false\n";
-        const DiseaseSpread* ds = model();
+        const State* st = eval_state();
         size_t off, len;
-        if (!ds || rec.mean.empty() || !sampled_range(*ds, coordName, off, len)) return {};
+        if (!st || rec.mean.empty() || !st->out_range(coordName, off, len)) return {};
         return std::vector<Float>(rec.mean.begin() + off, rec.mean.begin() + off + len);
     }
     /* returns row-major [nSamples][len]; len through *lenOut */
     std::vector<Float> get_samples(const std::string& coordName, size_t* lenOut) {
         *lenOut = 0;
         if (!haveSamples || rec.ics.empty()) { std::cout << "Requested samples, but none are present\n"; return {}; }
-        const DiseaseSpread* ds = model();
+        State* st = eval_state();
         size_t off, len;
         std::vector<Float> out;
-        if (sampled_range(*ds, coordName, off, len)) {
+        if (st->out_range(coordName, off, len)) {
             for (auto& x : rec.ics) out.insert(out.end(), x.begin() + off, x.begin() + off + len);
             *lenOut = len;
             return out;
         }
-        static const char* order[9] = {"mildlyInfectious", "highlyInfectious", "incubating", "asymptomatic", "mild",
-                                       "serious", "recovered", "dead", "totalBehavior"};
-        const size_t size = ds->nDaysTotal();
-        if (coordName == "capacity") {
-            auto cap = ds->getCoords("capacity");
-            for (size_t i = 0; i < rec.ics.size(); ++i) out.insert(out.end(), cap->begin(), cap->end());
-            *lenOut = size;
-            return out;
-        }
-        for (int c = 0; c < 9; ++c) {
-            if (coordName != order[c]) continue;
-            /* derived output coords: computed now, for the saved samples only (the
-             * compute_derived_late idea, mcmc.h:100-104) */
-            State* st = evalState ? evalState.get() : target->state.get();
-            Engine eng(*st->disease(), st->prior(), target->spec());
-            const size_t n = rec.ics.size();
-            std::vector<Float> flat;
-            for (auto& x : rec.ics) flat.insert(flat.end(), x.begin(), x.end());
-            std::vector<Float> curves(n * 9 * size);
-            hip_check(mcmc_hip_derive(eng.ctx, (int64_t)n, flat.data(), curves.data()), "mcmc_hip_derive");
-            for (size_t i = 0; i < n; ++i)
-                out.insert(out.end(), curves.begin() + (i * 9 + c) * size, curves.begin() + (i * 9 + c + 1) * size);
-            *lenOut = size;
-            return out;
+        const DiseaseSpread* ds = st->disease();
+        if (ds) {
+            static const char* order[9] = {"mildlyInfectious", "highlyInfectious", "incubating", "asymptomatic", "mild",
+                                           "serious", "recovered", "dead", "totalBehavior"};
+            const size_t size = ds->nDaysTotal();
+            if (coordName == "capacity") {
+                auto cap = ds->getCoords("capacity");
+                for (size_t i = 0; i < rec.ics.size(); ++i) out.insert(out.end(), cap->begin(), cap->end());
+                *lenOut = size;
+                return out;
+            }
+            for (int c = 0; c < 9; ++c) {
+                if (coordName != order[c]) continue;
+                /* derived output coords: computed now, for the saved samples only (the
+                 * compute_derived_late idea, mcmc.h:100-104) */
+                std::unique_ptr<Backend> be = st->backend(target->spec());
+                const size_t n = rec.ics.size();
+                std::vector<Float> flat;
+                for (auto& x : rec.ics) flat.insert(flat.end(), x.begin(), x.end());
+                std::vector<Float> curves(n * 9 * size);
+                be->derive(n, flat.data(), curves.data());
+                for (size_t i = 0; i < n; ++i)
+                    out.insert(out.end(), curves.begin() + (i * 9 + c) * size, curves.begin() + (i * 9 + c + 1) * size);
+                *lenOut = size;
+                return out;
+            }
         }
         std::cout << "Requested samples of unknown coordinate " << coordName << "\n";
         return {};
@@ -602,87 +814,30 @@ public:
         return rec.loglikes;
     }
 
-    /* pulls what chain `index` of a finished run recorded out of the engine */
-    static void collect(Engine& eng, int64_t index, int nSaved, bool samples, bool mean, ChainRecord& r) {
-        const int64_t n = mcmc_hip_n_chains(eng.ctx);
-        const int dim = eng.dim;
-        r.loglikes.assign(nSaved, 0);
-        if (nSaved > 0) {
-            std::vector<Float> all((size_t)n * nSaved);
-            hip_check(mcmc_hip_get_loglikes(eng.ctx, all.data()), "mcmc_hip_get_loglikes");
-            std::copy(all.begin() + index * nSaved, all.begin() + (index + 1) * nSaved, r.loglikes.begin());
-        }
-        r.ics.clear();
-        if (samples && nSaved > 0) {
-            std::vector<Float> s((size_t)nSaved * dim);
-            hip_check(mcmc_hip_get_samples(eng.ctx, index, 0, dim, s.data()), "mcmc_hip_get_samples");
-            for (int i = 0; i < nSaved; ++i) r.ics.emplace_back(s.begin() + (size_t)i * dim, s.begin() + (size_t)(i + 1) * dim);
-        }
-        std::vector<Float> buf((size_t)n * dim);
-        if (mean) {
-            hip_check(mcmc_hip_get_mean(eng.ctx, buf.data()), "mcmc_hip_get_mean");
-            r.mean.assign(buf.begin() + index * dim, buf.begin() + (index + 1) * dim);
-        }
-        hip_check(mcmc_hip_get_params(eng.ctx, buf.data()), "mcmc_hip_get_params");
-        r.finalParams.assign(buf.begin() + index * dim, buf.begin() + (index + 1) * dim);
-        std::vector<Float> ll((size_t)n * 2), ss(n);
-        std::vector<int32_t> acc(n);
-        hip_check(mcmc_hip_get_loglike(eng.ctx, ll.data()), "mcmc_hip_get_loglike");
-        hip_check(mcmc_hip_get_stepsizes(eng.ctx, ss.data()), "mcmc_hip_get_stepsizes");
-        hip_check(mcmc_hip_get_accept_counts(eng.ctx, acc.data()), "mcmc_hip_get_accept_counts");
-        r.finalLL[0] = ll[2 * index]; r.finalLL[1] = ll[2 * index + 1];
-        r.stepsize = ss[index];
-        r.nAccept = acc[index];
-    }
-
-    /* the chain's end state becomes the target's state, as after the reference's run() */
-    void apply_final_state(Engine& eng) {
-        DiseaseSpread* ds = target->state->disease();
-        ds->unpack(rec.finalParams.data());
-        ds->loglike = rec.finalLL[0];
-        ds->stepsizeCorrectionFac = rec.stepsize;
-        if (target->state->prior()) target->state->prior()->loglike = rec.finalLL[1];
-        std::vector<Float> curves((size_t)9 * eng.size);
-        hip_check(mcmc_hip_derive(eng.ctx, 1, rec.finalParams.data(), curves.data()), "mcmc_hip_derive");
-        ds->set_derived(curves.data());
-    }
-
 private:
     std::shared_ptr<State> evalState;
 
-    const DiseaseSpread* model() const {
-        const State* st = evalState ? evalState.get() : (target ? target->state.get() : nullptr);
-        return st ? st->disease() : nullptr;
-    }
-    static bool sampled_range(const DiseaseSpread& ds, const std::string& name, size_t& off, size_t& len) {
-        static const char* order[5] = {"behavior", "discontinuousVals", "betaMild", "betaHigh", "delay"};
-        off = 0;
-        for (int k = 0; k < 5; ++k) {
-            len = ds.getCoords()[k].size();
-            if (name == order[k]) return true;
-            off += len;
-        }
-        return false;
-    }
+    State* eval_state() const { return evalState ? evalState.get() : (target ? target->state.get() : nullptr); }
+
     /* text dump in the reference's format (mcmc.h:1013-1019, 1047-1059, 1163-1184) */
-    void write_samples(Engine& eng) {
+    void write_samples(Backend& be) {
         std::stringstream filename;
         filename << "samples" << id << ".txt";
         std::ofstream file(filename.str());
         file << "chainweight = " << weight << "\n\n";
-        State* st = evalState ? evalState.get() : target->state.get();
-        std::shared_ptr<State> work = st->deep_copy();
-        DiseaseSpread* ds = work->disease();
-        const size_t n = rec.ics.size();
+        std::shared_ptr<State> work = eval_state()->deep_copy();
+        const size_t n = rec.ics.size(), d = be.dim(), no = be.n_out();
         if (n == 0) return;
         std::vector<Float> flat;
-        for (auto& x : rec.ics) flat.insert(flat.end(), x.begin(), x.end());
-        std::vector<Float> curves(n * 9 * eng.size), ll(n * 2);
-        hip_check(mcmc_hip_derive(eng.ctx, (int64_t)n, flat.data(), curves.data()), "mcmc_hip_derive");
-        hip_check(mcmc_hip_eval(eng.ctx, (int64_t)n, flat.data(), ll.data()), "mcmc_hip_eval");
+        for (auto& x : rec.ics) flat.insert(flat.end(), x.begin(), x.begin() + d);
+        std::vector<Float> ll(n * 2), curves;
+        be.eval(n, flat.data(), ll.data());
+        DiseaseSpread* ds = work->disease();
+        if (ds) { curves.resize(n * 9 * be.curve_len()); be.derive(n, flat.data(), curves.data()); }
+        (void)no;
         for (size_t i = 0; i < n; ++i) {
-            ds->unpack(rec.ics[i].data());
-            ds->set_derived(curves.data() + i * 9 * eng.size);
+            work->set_packed(rec.ics[i].data());
+            if (ds) ds->set_derived(curves.data() + i * 9 * be.curve_len());
             file << "weight " << 1.0 << " loglike " << ll[2 * i] + ll[2 * i + 1] << "\n";
             for (auto& [name, vec] : work->get_all()) {
                 file << name << " ";
@@ -696,24 +851,25 @@ private:
 
 /* ------------------------------------------------------------------ ChainManager ---- */
 /* mcmc.h:1314-1655 for ChainType = MetropolisChain.  The per-chain set-up loop and the
- * tbb::parallel_for of run_all / run_all_adjust become one mcmc_hip_set_chains +
- * mcmc_hip_run over all chains; chain i keeps id i+1 (mcmc.h:1487,1527).  The reservoir
- * constructors evaluate their candidates in one batched mcmc_hip_eval. */
+ * tbb::parallel_for of run_all / run_all_adjust become one batched device run over all
+ * chains; chain i keeps id i+1 (mcmc.h:1487,1527).  The reservoir constructors evaluate
+ * their candidates in batches on the device. */
 class ChainManager {
 public:
     using ICs = std::vector<std::vector<Float>>;
 
-    /* mcmc.h:1317-1347.  DiseaseSpread does not implement sampleInitialConditions, so the
-     * reference's loop pushes the state's current initial conditions nChain times. */
+    /* mcmc.h:1317-1347: draw initial conditions until nChain have a finite log probability.
+     * (DiseaseSpread and MyLike1 do not implement sampleInitialConditions, so every draw
+     * is the state's current point.) */
     ChainManager(std::shared_ptr<Target> target, size_t nChain) : target(target), nChain(nChain) {
+        pcg32 rnd(0, 0);
         std::cout << "\nConstructing " << nChain << " random inital states. " << std::endl;
         target->set_posterior(target->state);
-        const Float prob = target->logprobability(0);
-        if (std::isnan(prob) || std::isinf(prob))
-            throw std::runtime_error("ChainManager: the state's log probability is not finite, no initial state can be drawn");
-        for (size_t i = 0; i < nChain; ++i) {
-            std::cout << "Logprobabilty of state " << i << " is " << prob << "\n";
-            chainICs.push_back(std::make_pair(target->state->getInitialConditions(), 1));
+        std::vector<std::pair<ICs, Float>> got;
+        draw_candidates(rnd, nChain, got);
+        for (size_t i = 0; i < got.size(); ++i) {
+            std::cout << "Logprobabilty of state " << i << " is " << got[i].second << "\n";
+            chainICs.push_back(std::make_pair(got[i].first, 1));
         }
         stepsizes = std::vector<Float>(target->state->state.size(), Float(1));
     }
@@ -722,9 +878,10 @@ public:
         pcg32 rnd(0, 0);
         std::cout << "\nConstructing a discrete distribution of " << nChainReservoir << " random inital states. " << std::endl;
         if (!target->state->isInitialized) target->state->init();
-        std::vector<ICs> cand(nChainReservoir, target->state->getInitialConditions());
-        build_from_candidates(rnd, cand, std::vector<Float>(nChainReservoir, 0.0));
+        std::vector<std::pair<ICs, Float>> trial;
+        draw_candidates(rnd, nChainReservoir, trial);
         stepsizes = std::vector<Float>(target->state->state.size(), Float(1));
+        bootstrap(rnd, trial);
     }
     /* mcmc.h:1376-1418: seed the chains from the recorded points of a generator chain,
      * re-weighted to the new target */
@@ -735,20 +892,25 @@ public:
             std::cout << "Re-evaluating chain samples for their likelihood given the current target. This is as many times quicker as the original chain as the thinning.\n";
         if (generator->rec.ics.empty()) throw std::runtime_error("ChainManager: the generator chain holds no recorded points");
         if (!target->state->isInitialized) target->state->init();
+        const size_t d = target->state->packed().size();
         std::vector<ICs> cand;
         for (auto& x : generator->rec.ics) {
-            ICs ic = {x};
+            if (x.size() < d) throw std::invalid_argument("ChainManager: generator point with wrong dimension");
+            ICs ic = {std::vector<Float>(x.begin(), x.begin() + d)};
             for (size_t i = 1; i < target->state->state.size(); ++i) ic.push_back({});
             cand.push_back(ic);
         }
-        build_from_candidates(rnd, cand, generator->rec.loglikes);
+        std::vector<std::pair<ICs, Float>> trial;
+        weigh_candidates(cand, generator->rec.loglikes, trial);
+        if (trial.empty()) throw std::runtime_error("ChainManager: no candidate has a finite log probability");
         stepsizes = generator->target->state->get_stepsizes();
+        bootstrap(rnd, trial);
     }
 
     std::vector<Float> stepsizes;
 
     /* user-supplied initial conditions [nChain][dim], each with weight 1: what a caller
-     * does who diversifies the chains himself (the reference has no way to, see above) */
+     * does who diversifies the chains himself (DiseaseSpread has no way to, see above) */
     void set_initial_conditions(const std::vector<std::vector<Float>>& x) {
         chainICs.clear();
         for (auto& v : x) {
@@ -794,14 +956,14 @@ public:
         std::cout << "Reevaluation completed." << std::endl << std::endl;
     }
     size_t n_chains() const { return chainICs.size(); }
-    /* bulk views of the last run, chain-major: loglikes [n][nSaved], saved sample s [n][dim] */
+    /* bulk views of the last run, chain-major: loglikes [n][nSaved], saved sample s [n][nOut] */
     const std::vector<Float>& all_loglikes() const { return R.lls; }
     const std::vector<Float>& all_final_params() const { return R.params; }
     const std::vector<Float>& saved_sample(int s) const { return R.saved.at(s); }
     int n_saved() const { return R.nSaved; }
-    int n_dim() const { return (int)R.dim; }
+    int n_dim() const { return (int)R.nOut; }
     int chain_weight(size_t i) const { return chainICs.at(i).second; }
-    /* acceptance counts, step sizes ... of the last run, for diagnostics */
+    /* acceptance counts, sums ... of the last run (mcmc_hip_diagnostics), covid states only */
     std::vector<Float> last_diagnostics;
 
 protected:
@@ -809,24 +971,46 @@ protected:
     size_t nChain = 1;
     std::vector<std::pair<ICs, int>> chainICs;
 
-    /* evaluates log p_target(candidate) - oldlogprob in one batch, then bootstraps */
-    void build_from_candidates(pcg32& rnd, const std::vector<ICs>& cand, const std::vector<Float>& oldlogprob) {
-        DiseaseSpread* ds = target->state->disease();
-        Engine eng(*ds, target->state->prior(), target->spec());
-        const size_t n = cand.size(), dim = (size_t)eng.dim;
+    /* log p_target(candidate) - oldlogprob for a batch of candidates, finite ones kept in order */
+    void weigh_candidates(const std::vector<ICs>& cand, const std::vector<Float>& oldlogprob,
+                          std::vector<std::pair<ICs, Float>>& out) {
+        std::unique_ptr<Backend> be = target->state->backend(target->spec());
+        const size_t n = cand.size(), dim = be->dim();
         std::vector<Float> flat(n * dim), ll(n * 2);
         for (size_t i = 0; i < n; ++i) {
             if (cand[i][0].size() != dim) throw std::invalid_argument("ChainManager: candidate with wrong dimension");
             std::copy(cand[i][0].begin(), cand[i][0].end(), flat.begin() + i * dim);
         }
-        hip_check(mcmc_hip_eval(eng.ctx, (int64_t)n, flat.data(), ll.data()), "mcmc_hip_eval");
-        std::vector<std::pair<ICs, Float>> trial;
+        be->eval(n, flat.data(), ll.data());
         for (size_t i = 0; i < n; ++i) {
             const Float prob = std::log(target->weight()) + target->beta(0) * (ll[2 * i] + ll[2 * i + 1]);
-            if (!std::isnan(prob) && !std::isinf(prob)) trial.push_back(std::make_pair(cand[i], prob - oldlogprob[i]));
+            if (!std::isnan(prob) && !std::isinf(prob)) out.push_back(std::make_pair(cand[i], prob - oldlogprob[i]));
         }
-        if (trial.empty()) throw std::runtime_error("ChainManager: no candidate has a finite log probability");
-        bootstrap(rnd, trial);
+    }
+    /* the `while (size < want) { sampleInitialConditions; eval; keep if finite }` loops of
+     * mcmc.h:1324-1343,1356-1371: the draws come from rnd in the reference's order and are
+     * evaluated in batches */
+    void draw_candidates(pcg32& rnd, size_t want, std::vector<std::pair<ICs, Float>>& out) {
+        State& st = *target->state;
+        ToyLikelihood* t = st.toy();
+        size_t rounds = 0;
+        while (out.size() < want) {
+            const size_t need = want - out.size();
+            std::vector<ICs> cand;
+            for (size_t i = 0; i < need; ++i) {
+                if (t) t->sampleInitialConditions(rnd);
+                ICs ic = {st.packed()};
+                for (size_t k = 1; k < st.state.size(); ++k) ic.push_back({});
+                cand.push_back(ic);
+            }
+            const size_t before = out.size();
+            weigh_candidates(cand, std::vector<Float>(need, 0.0), out);
+            /* a likelihood that cannot draw gives the same point every time: the
+             * reference would loop forever on a non-finite one */
+            if (out.size() == before && (!t || ++rounds > 1000))
+                throw std::runtime_error("ChainManager: the state's log probability is not finite, no initial state can be drawn");
+        }
+        if (t) st.setInitialConditions(out.back().first);
     }
 
     /* mcmc.h:1599-1650: draw nChain distinct candidates from the discrete distribution of
@@ -867,37 +1051,19 @@ protected:
 
     /* what the last batched run recorded, for all chains; a MetropolisChain object (with its
      * own deep-copied Target, mcmc.h:1479,1520) is only built when somebody asks for it */
-    struct Results {
-        size_t n = 0, dim = 0;
-        int nSaved = 0;
-        std::vector<Float> lls, params, mean, fll, fss;
-        std::vector<int32_t> acc;
-        std::vector<std::vector<Float>> saved;
-    } R;
+    BatchResults R;
     size_t nRun = 0;
     std::map<size_t, MetropolisChain> chains;
 
     MetropolisChain& materialize(size_t i) {
         auto it = chains.find(i);
         if (it != chains.end()) return it->second;
-        const size_t dim = R.dim;
-        const int nSaved = R.nSaved;
         std::shared_ptr<Target> tar = target->deep_copy();
         MetropolisChain c(tar, (int)i + 1);
         c.recordSamples = false;
         c.weight = chainICs[i].second;
-        c.rec.loglikes.assign(R.lls.begin() + i * nSaved, R.lls.begin() + (i + 1) * nSaved);
-        for (int s = 0; s < nSaved; ++s) c.rec.ics.emplace_back(R.saved[s].begin() + i * dim, R.saved[s].begin() + (i + 1) * dim);
-        c.rec.mean.assign(R.mean.begin() + i * dim, R.mean.begin() + (i + 1) * dim);
-        c.rec.finalParams.assign(R.params.begin() + i * dim, R.params.begin() + (i + 1) * dim);
-        c.rec.finalLL[0] = R.fll[2 * i]; c.rec.finalLL[1] = R.fll[2 * i + 1];
-        c.rec.stepsize = R.fss[i];
-        c.rec.nAccept = R.acc[i];
-        DiseaseSpread* cds = tar->state->disease();
-        cds->unpack(c.rec.finalParams.data());
-        cds->loglike = R.fll[2 * i];
-        cds->stepsizeCorrectionFac = R.fss[i];
-        if (tar->state->prior()) tar->state->prior()->loglike = R.fll[2 * i + 1];
+        c.rec.take(R, i);
+        c.rec.apply_to(*tar->state);
         return chains.emplace(i, std::move(c)).first->second;
     }
 
@@ -909,41 +1075,26 @@ protected:
         if (thinning < 1) { std::cout << "ChainManager: thinning must be at least 1.\n"; return; }
         const size_t n = chainICs.size();
         if (n == 0) { std::cout << "ChainManager: no initial conditions.\n"; return; }
-        DiseaseSpread* ds = target->state->disease();
-        Engine eng(*ds, target->state->prior(), target->spec());
-        const size_t dim = (size_t)eng.dim;
+        State& st = *target->state;
+        std::unique_ptr<Backend> be = st.backend(target->spec());
+        const size_t dim = be->dim();
         std::vector<Float> flat(n * dim);
-        for (size_t i = 0; i < n; ++i) std::copy(chainICs[i].first[0].begin(), chainICs[i].first[0].end(), flat.begin() + i * dim);
+        for (size_t i = 0; i < n; ++i) {
+            if (chainICs[i].first[0].size() != dim) { std::cout << "ChainManager: initial condition " << i << " has the wrong dimension.\n"; return; }
+            std::copy(chainICs[i].first[0].begin(), chainICs[i].first[0].end(), flat.begin() + i * dim);
+        }
         /* run_all applies the manager's step sizes, run_all_adjust starts from the target
          * state's own (mcmc.h:1483 vs 1523) */
-        const Float ss0 = useStepsizes ? (stepsizes.empty() ? 1.0 : stepsizes[0]) : ds->stepsizeCorrectionFac;
+        const Float ss0 = useStepsizes ? (stepsizes.empty() ? 1.0 : stepsizes[0]) : st.state[0]->stepsizeCorrectionFac;
         std::vector<Float> ss(n, ss0);
-        hip_check(mcmc_hip_set_chains(eng.ctx, (int64_t)n, flat.data(), ss.data(), nullptr, 1), "mcmc_hip_set_chains");
         {
             std::vector<Float> ll(n * 2);
-            hip_check(mcmc_hip_get_loglike(eng.ctx, ll.data()), "mcmc_hip_get_loglike");
+            be->eval(n, flat.data(), ll.data());
             for (size_t i = 0; i < n; ++i)
                 std::cout << "Initialized chain " << i << " with true loglikelihood = " << ll[2 * i] + ll[2 * i + 1] << "\n";
         }
-        /* the parameter samples are what the reference keeps as `ics` of every saved point
-         * (mcmc.h:1042-1045) even though recordSamples is forced off (mcmc.h:1490,1530) */
-        hip_check(mcmc_hip_run(eng.ctx, nSteps, 0, nAdjust, thinning, 1, 1), "mcmc_hip_run");
-        const int nSaved = mcmc_hip_n_saved(nSteps, 0, nAdjust, thinning);
-        /* bulk download, then split per chain */
-        R = Results{};
-        R.lls.assign(n * (size_t)std::max(nSaved, 1), 0); R.params.assign(n * dim, 0); R.mean.assign(n * dim, 0);
-        R.fll.assign(n * 2, 0); R.fss.assign(n, 0); R.acc.assign(n, 0);
-        if (nSaved > 0) hip_check(mcmc_hip_get_loglikes(eng.ctx, R.lls.data()), "mcmc_hip_get_loglikes");
-        hip_check(mcmc_hip_get_params(eng.ctx, R.params.data()), "mcmc_hip_get_params");
-        hip_check(mcmc_hip_get_mean(eng.ctx, R.mean.data()), "mcmc_hip_get_mean");
-        hip_check(mcmc_hip_get_loglike(eng.ctx, R.fll.data()), "mcmc_hip_get_loglike");
-        hip_check(mcmc_hip_get_stepsizes(eng.ctx, R.fss.data()), "mcmc_hip_get_stepsizes");
-        hip_check(mcmc_hip_get_accept_counts(eng.ctx, R.acc.data()), "mcmc_hip_get_accept_counts");
-        R.saved.assign(nSaved, std::vector<Float>(n * dim));
-        for (int s = 0; s < nSaved; ++s) hip_check(mcmc_hip_get_sample_all(eng.ctx, s, R.saved[s].data()), "mcmc_hip_get_sample_all");
-        last_diagnostics.assign(4 + 2 * dim, 0);
-        hip_check(mcmc_hip_diagnostics(eng.ctx, last_diagnostics.data()), "mcmc_hip_diagnostics");
-        R.n = n; R.dim = dim; R.nSaved = nSaved;
+        be->run(R, n, flat.data(), ss.data(), 1, nSteps, 0, nAdjust, thinning);
+        last_diagnostics = R.diagnostics;
         nRun = n;
         std::cout << "Chain runs completed." << std::endl << std::endl;
     }

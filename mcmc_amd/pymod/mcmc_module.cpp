@@ -7,8 +7,10 @@
  * Names, argument orders and quirks are the reference's: `Chain` is MetropolisChain,
  * `ChainManager.run_all` is bound to run_all_adjust and `run_all_adjust` to run_all
  * (test.cpp:124-125), `SubspaceState.getCoords` is getCoordsAt (test.cpp:51).
- * Classes of the reference that are not on the covid path (A-D, FourGaussians, the
- * distfind.h PDFs, AdvCoolingTarget, GradientDecent) are not part of this module.
+ * The toy targets of test.h that BASELINE configs[0] names are here too: FourGaussians
+ * (test.cpp:63-64), MyState (test.cpp:79-81) and its MyLike1.  Classes of the reference off
+ * that path (A-D, the distfind.h PDFs, AdvCoolingTarget, GradientDecent) are not part of
+ * this module.
  */
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
@@ -37,6 +39,11 @@ PYBIND11_MODULE(mcmc, m) {
         .def_readwrite("stepsizeCorrectionFac", &SubspaceState::stepsizeCorrectionFac);
     py::class_<SmoothnessPrior, SubspaceState, std::shared_ptr<SmoothnessPrior>>(m, "SmoothnessPrior")
         .def(py::init<const std::string&, Float, Float>());
+
+    py::class_<MyLike1, SubspaceState, std::shared_ptr<MyLike1>>(m, "MyLike1")
+        .def(py::init<>());
+    py::class_<FourGaussians, SubspaceState, std::shared_ptr<FourGaussians>>(m, "FourGaussians")
+        .def(py::init<Float>());
 
     py::class_<DiseaseParams>(m, "DiseaseParams")
         .def(py::init<>())
@@ -98,6 +105,9 @@ PYBIND11_MODULE(mcmc, m) {
         .def("force_bounds", &State::force_bounds)
         .def("get_all", &State::get_all)
         .def_readwrite("sharedDependencyMaxDepth", &State::sharedDependencyMaxDepth);
+
+    py::class_<MyState, State, std::shared_ptr<MyState>>(m, "MyState")
+        .def(py::init<>());
 
     py::class_<Target, std::shared_ptr<Target>>(m, "Target")
         .def(py::init<>())

@@ -606,12 +606,17 @@ typedef void (*toy_prop_fn)(orc_pcg32* r, const double* x, double sf, double* xp
 
 static int toy_run(int dimx, toy_eval_fn ev, toy_prop_fn pr, const void* ud, double beta,
                    int chain_id, double* x, int nSamples, int nBurnin, int nAdjust, int thinning,
-                   double* loglikes_out, double* samples_out, double* stepsize_out, int* n_accept_out) {
+                   double* loglikes_out, double* samples_out, double* stepsize_out, int* n_accept_out,
+                   double* mean_out /* [dimx + with_max] or NULL */, int with_max, double stepsize0) {
     orc_pcg32 rng;
     orc_pcg32_seed(&rng, 0, (uint64_t)chain_id);
-    double xp[8];
-    double ll = ev(x, ud), sf = 1.0;
+    double xp[8], mean[9];
+    double ll = ev(x, ud), sf = stepsize0;
     int nAccept = 0, n_saved = 0;
+    /* mean = deep copy of the evaluated state (mcmc.h:1002); MyLike1's eval also sets the
+     * coordinate "max" (test.h:37), which addCoordsOf sums like any other (mcmc.h:273-281) */
+    memcpy(mean, x, sizeof(double) * dimx);
+    if (with_max) mean[dimx] = fmax(fmax(x[0], x[1]), x[2]);
     for (int i = 0; i < nSamples + nAdjust; ++i) {
         if (i == nAdjust) nAccept = 0;
         if ((i >= nBurnin) && (i % thinning) == 0) {
@@ -619,6 +624,10 @@ static int toy_run(int dimx, toy_eval_fn ev, toy_prop_fn pr, const void* ud, dou
             if (loglikes_out) loglikes_out[n_saved] = log(1.0) + beta * l;
             if (samples_out) memcpy(samples_out + (size_t)n_saved * dimx, x, sizeof(double) * dimx);
             ++n_saved;
+        }
+        if (i > nBurnin && mean_out) {                              /* mcmc.h:1064-1065 */
+            for (int k = 0; k < dimx; ++k) mean[k] += x[k];
+            if (with_max) mean[dimx] += fmax(fmax(x[0], x[1]), x[2]);
         }
         int reps = 1;
         if (i < nAdjust) { nAccept = 0; reps = 20; }
@@ -640,6 +649,11 @@ static int toy_run(int dimx, toy_eval_fn ev, toy_prop_fn pr, const void* ud, dou
     }
     if (stepsize_out) *stepsize_out = sf;
     if (n_accept_out) *n_accept_out = nAccept;
+    if (mean_out) {                                                 /* mcmc.h:1133-1134 */
+        const int cnt = nAdjust + nSamples - nBurnin;
+        const double f = cnt != 0 ? 1.0 / (double)cnt : 1.0;
+        for (int k = 0; k < dimx + (with_max ? 1 : 0); ++k) mean_out[k] = mean[k] * f;
+    }
     return n_saved;
 }
 
@@ -657,10 +671,11 @@ static void mylike1_prop(orc_pcg32* r, const double* x, double sf, double* xp, c
     for (int j = 0; j < 3; ++j) xp[j] = x[j] + 10 * sf * (orc_pcg32_next_float(r) - 0.5); /* test.h:50 */
 }
 int orc_mylike1_run(int chain_id, int nSamples, int nBurnin, int nAdjust, int thinning,
-                    double* loglikes_out, double* samples_out, double* stepsize_out, int* n_accept_out) {
+                    double* loglikes_out, double* samples_out, double* stepsize_out, int* n_accept_out,
+                    double* mean_out /* [4]: position, max */) {
     double x[3] = {1, 1, 1};                                        /* test.h:20 */
     return toy_run(3, mylike1_eval, mylike1_prop, NULL, 1.0, chain_id, x, nSamples, nBurnin,
-                   nAdjust, thinning, loglikes_out, samples_out, stepsize_out, n_accept_out);
+                   nAdjust, thinning, loglikes_out, samples_out, stepsize_out, n_accept_out, mean_out, 1, 1.0);
 }
 
 /* FourGaussians (test.h:69-136) */
@@ -684,10 +699,11 @@ static void fourg_prop(orc_pcg32* r, const double* x, double sf, double* xp, con
 }
 int orc_fourgauss_run(double difficulty, double T, int chain_id, const double* x0, int nSamples,
                       int nBurnin, int nAdjust, int thinning, double* loglikes_out,
-                      double* samples_out, double* stepsize_out, int* n_accept_out) {
+                      double* samples_out, double* stepsize_out, int* n_accept_out, double* mean_out /* [2] */,
+                      double stepsize0) {
     double x[2] = {x0 ? x0[0] : 0.0, x0 ? x0[1] : 0.0};             /* test.h:75 */
     return toy_run(2, fourg_eval, fourg_prop, &difficulty, 1 / T, chain_id, x, nSamples, nBurnin,
-                   nAdjust, thinning, loglikes_out, samples_out, stepsize_out, n_accept_out);
+                   nAdjust, thinning, loglikes_out, samples_out, stepsize_out, n_accept_out, mean_out, 0, stepsize0);
 }
 
 /* mcmc_detmath.h entry points, exported so that tests can compare them with libm */

@@ -161,15 +161,16 @@ double orc_run_chains(const orc_covid_model* m, const orc_target* t, int n_chain
 
 /* ---- toy targets of test.h (config 0: CLI run test.cpp:27-40) ---- */
 /* MyLike1 (test.h:14-67), 3-D Gaussian, chain id, run(nSamples,nBurnin,nAdjust,thinning);
- * returns n_saved; samples_out [n_saved][3], loglikes_out [n_saved] */
+ * returns n_saved; samples_out [n_saved][3], loglikes_out [n_saved], mean_out [4] (position and
+ * the coordinate "max", mcmc.h:1002,1064-1065,1133-1134; may be NULL) */
 int orc_mylike1_run(int chain_id, int nSamples, int nBurnin, int nAdjust, int thinning,
                     double* loglikes_out, double* samples_out, double* stepsize_out,
-                    int* n_accept_out);
-/* FourGaussians (test.h:69-136) under TempTarget(T) */
+                    int* n_accept_out, double* mean_out);
+/* FourGaussians (test.h:69-136) under TempTarget(T), from x0 with stepsizeCorrectionFac stepsize0 */
 int orc_fourgauss_run(double difficulty, double T, int chain_id, const double* x0,
                       int nSamples, int nBurnin, int nAdjust, int thinning,
                       double* loglikes_out, double* samples_out, double* stepsize_out,
-                      int* n_accept_out);
+                      int* n_accept_out, double* mean_out /* [2] or NULL */, double stepsize0);
 
 /* include/mcmc_detmath.h, exported for tests */
 double orc_det_cos(double x);

@@ -117,10 +117,10 @@ def lib():
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp,
                                  C.POINTER(C.c_int), C.POINTER(C.c_uint64), dp]
     L.orc_run_chains.restype = C.c_double
-    L.orc_mylike1_run.argtypes = [C.c_int] * 5 + [dp, dp, dp, C.POINTER(C.c_int)]
+    L.orc_mylike1_run.argtypes = [C.c_int] * 5 + [dp, dp, dp, C.POINTER(C.c_int), dp]
     L.orc_mylike1_run.restype = C.c_int
     L.orc_fourgauss_run.argtypes = [C.c_double, C.c_double, C.c_int, dp] + [C.c_int] * 4 + \
-                                   [dp, dp, dp, C.POINTER(C.c_int)]
+                                   [dp, dp, dp, C.POINTER(C.c_int), dp, C.c_double]
     L.orc_fourgauss_run.restype = C.c_int
     L.orc_det_cos.argtypes = [C.c_double]
     L.orc_det_cos.restype = C.c_double
@@ -296,18 +296,18 @@ def run_chains(model: Model, target, x0, stepsizes, nSamples, nBurnin, nAdjust, 
                 steps=n * (20 * nAdjust + nSamples))
 
 
-def mylike1_run(chain_id, nSamples, nBurnin, nAdjust, thinning):
+def mylike1_run(chain_id, nSamples, nBurnin, nAdjust, thinning, with_mean=False):
     n = lib().orc_n_saved(nSamples, nBurnin, nAdjust, thinning)
-    ll = np.zeros(n); s = np.zeros((n, 3)); sf = C.c_double(); na = C.c_int()
+    ll = np.zeros(n); s = np.zeros((n, 3)); sf = C.c_double(); na = C.c_int(); mean = np.zeros(4)
     lib().orc_mylike1_run(chain_id, nSamples, nBurnin, nAdjust, thinning, _dp(ll), _dp(s),
-                          C.byref(sf), C.byref(na))
-    return ll, s, sf.value, na.value
+                          C.byref(sf), C.byref(na), _dp(mean))
+    return (ll, s, sf.value, na.value, mean) if with_mean else (ll, s, sf.value, na.value)
 
 
-def fourgauss_run(difficulty, T, chain_id, x0, nSamples, nBurnin, nAdjust, thinning):
+def fourgauss_run(difficulty, T, chain_id, x0, nSamples, nBurnin, nAdjust, thinning, with_mean=False, stepsize=1.0):
     n = lib().orc_n_saved(nSamples, nBurnin, nAdjust, thinning)
-    ll = np.zeros(n); s = np.zeros((n, 2)); sf = C.c_double(); na = C.c_int()
+    ll = np.zeros(n); s = np.zeros((n, 2)); sf = C.c_double(); na = C.c_int(); mean = np.zeros(2)
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     lib().orc_fourgauss_run(difficulty, T, chain_id, _dp(x0), nSamples, nBurnin, nAdjust, thinning,
-                            _dp(ll), _dp(s), C.byref(sf), C.byref(na))
-    return ll, s, sf.value, na.value
+                            _dp(ll), _dp(s), C.byref(sf), C.byref(na), _dp(mean), stepsize)
+    return (ll, s, sf.value, na.value, mean) if with_mean else (ll, s, sf.value, na.value)

@@ -12,10 +12,12 @@ pytestmark = pytest.mark.gpu
 def test_mylike1_cli_config_bitexact():
     """test.cpp:36-38: MyState, chain id 0, run(100000, 10, 500, 5)."""
     r = H.toy_run("mylike1", [[1.0, 1.0, 1.0]], 100000, 10, 500, 5, first_chain_id=0)
-    ll, s, sf, nacc = O.mylike1_run(0, 100000, 10, 500, 5)
-    assert np.array_equal(r["loglikes"][0], ll) and np.array_equal(r["samples"][0], s)
+    ll, s, sf, nacc, mean = O.mylike1_run(0, 100000, 10, 500, 5, with_mean=True)
+    assert np.array_equal(r["loglikes"][0], ll) and np.array_equal(r["samples"][0][:, :3], s)
+    assert np.array_equal(r["samples"][0][:, 3], s.max(axis=1))          # the coordinate "max", test.h:37
     assert r["stepsizes"][0] == sf and r["n_accept"][0] == nacc
-    post = r["samples"][0][200:]
+    assert np.array_equal(r["mean"][0], mean)
+    post = r["samples"][0][200:, :3]
     assert np.all(np.abs(post.mean(axis=0)) < 0.05) and np.all(np.abs(post.var(axis=0) - 0.5) < 0.05)
 
 
@@ -23,9 +25,9 @@ def test_mylike1_many_chains_and_ids():
     n = 300
     r = H.toy_run("mylike1", np.ones((n, 3)), 400, 0, 20, 4, first_chain_id=1)
     for c in (0, 63, 64, 299):
-        ll, s, sf, nacc = O.mylike1_run(c + 1, 400, 0, 20, 4)
-        assert np.array_equal(r["loglikes"][c], ll) and np.array_equal(r["samples"][c], s)
-        assert r["stepsizes"][c] == sf and r["n_accept"][c] == nacc
+        ll, s, sf, nacc, mean = O.mylike1_run(c + 1, 400, 0, 20, 4, with_mean=True)
+        assert np.array_equal(r["loglikes"][c], ll) and np.array_equal(r["samples"][c][:, :3], s)
+        assert r["stepsizes"][c] == sf and r["n_accept"][c] == nacc and np.array_equal(r["mean"][c], mean)
 
 
 @pytest.mark.parametrize("T", [1.0, 10.0])
@@ -34,9 +36,9 @@ def test_four_gaussians_tempered_bitexact(T):
     x0 = np.array([[0.0, 0.0], [1.0, 0.5], [-4.9, 4.9]])
     r = H.toy_run("fourgauss", x0, 3000, 5, 100, 10, difficulty=6.0, target="temp", T=T, chain_ids=[0, 5, 9])
     for i, cid in enumerate([0, 5, 9]):
-        ll, s, sf, nacc = O.fourgauss_run(6.0, T, cid, x0[i], 3000, 5, 100, 10)
+        ll, s, sf, nacc, mean = O.fourgauss_run(6.0, T, cid, x0[i], 3000, 5, 100, 10, with_mean=True)
         assert np.array_equal(r["loglikes"][i], ll) and np.array_equal(r["samples"][i], s)
-        assert r["stepsizes"][i] == sf and r["n_accept"][i] == nacc
+        assert r["stepsizes"][i] == sf and r["n_accept"][i] == nacc and np.array_equal(r["mean"][i], mean)
     assert np.all(np.abs(r["samples"]) <= 5.0)
 
 

@@ -24,7 +24,7 @@ def _data():
 
 def test_surface_names_match_the_reference():
     for name in ("SubspaceState", "SmoothnessPrior", "State", "Target", "TempTarget", "CoolingTarget", "Chain",
-                 "ChainManager", "DiseaseParams", "DiseaseData", "DiseaseSpread"):
+                 "ChainManager", "DiseaseParams", "DiseaseData", "DiseaseSpread", "FourGaussians", "MyState"):
         assert hasattr(mcmc, name)
     for meth in ("run", "get_mean", "get_samples", "get_weights", "get_loglikes", "reevaluate"):
         assert hasattr(mcmc.Chain, meth)
@@ -32,6 +32,9 @@ def test_surface_names_match_the_reference():
         assert hasattr(mcmc.ChainManager, meth)
     for meth in ("add", "init", "loglike", "force_bounds", "get_all"):
         assert hasattr(mcmc.State, meth)
+    fg = mcmc.FourGaussians(6)                                       # test.h:73-77
+    assert fg.get_names() == {"pos": 0} and fg.getCoords("pos") == [0, 0]
+    assert mcmc.MyLike1().getCoords("position") == [1, 1, 1]         # test.h:18-22
     p = mcmc.DiseaseParams()
     for k, v in CC.DISEASE_PARAMS_DEFAULT.items():                  # covid.h:75-90
         assert getattr(p, k) == v
@@ -94,3 +97,10 @@ def test_no_gpu_means_an_error_not_a_cpu_fallback(capfd):
     bad.add(mcmc.SmoothnessPrior("behavior", 50.0, 30.0))
     with pytest.raises(RuntimeError):
         bad.init()
+    # the toy states evaluate on the device too: MyState() runs init() (test.h:300-308)
+    with pytest.raises(mcmc.McmcHipError, match="no HIP device"):
+        mcmc.MyState()
+    fg = mcmc.State()
+    fg.add(mcmc.FourGaussians(6))
+    with pytest.raises(mcmc.McmcHipError, match="no HIP device"):
+        fg.init()
