@@ -84,6 +84,27 @@ def cpu_baseline(cfg, R10, xs, stepsizes, contract, seconds=20.0):
                       f"(oracle/mcmc_oracle.c, lean table, {threads} pthreads, {res['wall']:.1f} s)"}
 
 
+def ess_leg(cfg, R, device, contract, xs, stepsizes, first_id, n_steps, thinning):
+    """ESS per MH step of delay / betaMild / betaHigh from a recorded run of a
+    subset of the chains, continued from the adapted state.  Chains are bit-identical on the
+    CPU path, so ESS/s on either side = ESS per step x that side's steps/s."""
+    from mcmc_amd.sharding import ess_geyer
+    n = xs.shape[0]
+    s = H.CovidSampler(cfg, R, device)
+    s.set_chains(xs, stepsizes=stepsizes, first_chain_id=first_id)
+    s.run(n_steps, 0, 0, thinning, record_samples=True, compute_mean=False)
+    n_saved = s.n_saved
+    dim = cfg["dim"]
+    tail = np.stack([s.sample_all(k)[:, dim - 3:] for k in range(n_saved)], axis=1)    # [n][n_saved][3]
+    acc = s.accept_counts().mean() / n_steps
+    s.close()
+    names = ["betaMild", "betaHigh", "delay"]
+    per_step = {nm: float(ess_geyer(tail[:, :, j]).sum() / (n * n_steps)) for j, nm in enumerate(names)}
+    return {"ess_per_step": per_step, "acceptance": float(acc),
+            "sample": f"{n} chains x {n_steps} steps after the adaptation, every {thinning}th point, Geyer initial "
+                      "positive sequence per chain, summed over chains"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +115,8 @@ def main():
     ap.add_argument("--adjust", type=int, default=int(os.environ.get("MCMC_BENCH_ADJUST", "25")),
                     help="adjust-phase iterations (20 MH steps each, mcmc.h:1083-1119) run untimed before the warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ess-chains", type=int, default=4096, help="chains of the ESS leg (0: skip it)")
+    ap.add_argument("--ess-steps", type=int, default=2000)
     # rehearsal knobs: several ranks on ONE card need the gloo backend and a fixed device
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--device", type=int, default=None, help="HIP ordinal for every rank (default: LOCAL_RANK)")
@@ -128,7 +151,8 @@ def main():
     if args.adjust > 0:
         s.run(0, 0, args.adjust, 1000000)                # step-size adaptation only, nothing recorded
     s.step(args.warmup, 1.0, True)
-    cpu_start = (s.params()[:256].copy(), s.stepsizes()[:256].copy()) if rank == 0 else None
+    n_keep = max(256, min(args.ess_chains, n_chains))
+    cpu_start = (s.params()[:n_keep].copy(), s.stepsizes()[:n_keep].copy()) if rank == 0 else None
     s.pair_count(reset=True)
     t_before = s.last_timing()
     sync()
@@ -182,6 +206,14 @@ def main():
             cb = cpu_baseline(cfg, R, cpu_start[0], cpu_start[1], args.contract)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = value / cb["value"]
+        if world == 1 and args.ess_chains > 0:
+            ne = min(args.ess_chains, n_chains)
+            e = ess_leg(cfg, R, device, args.contract, cpu_start[0][:ne], cpu_start[1][:ne], first_id, args.ess_steps, 5)
+            worst = min(e["ess_per_step"].values())
+            e["gpu_ess_per_s"] = worst * value            # slowest-mixing of the three coordinates
+            if "cpu_baseline" in out:
+                e["cpu_ess_per_s"] = worst * out["cpu_baseline"]["value"]
+            out["ess"] = e
         print(json.dumps(out), flush=True)
     s.close()
     if dist is not None:

@@ -97,3 +97,24 @@ def rhat_ess(sums, k, n_saved, max_lag=0):
 def acceptance_from_diagnostics(diag_sum, n_chains_total, steps_per_chain):
     """diag vector of mcmc_hip_diagnostics (additive over shards) -> acceptance rate."""
     return diag_sum[0] / (n_chains_total * max(steps_per_chain, 1))
+
+
+def ess_geyer(series):
+    """Effective sample size of every chain by Geyer's initial positive sequence.
+
+    series: [n_chains, n] draws of one scalar.  Returns ess [n_chains] (n / tau, with
+    tau = -1 + 2 * sum of the leading positive pair sums rho[2t] + rho[2t+1]); a chain that
+    never moved has ESS 0.  Extension: the reference reports no ESS."""
+    s = np.asarray(series, dtype=np.float64)
+    m, n = s.shape
+    d = s - s.mean(axis=1, keepdims=True)
+    f = np.fft.rfft(d, 2 * n, axis=1)
+    acov = np.fft.irfft(f * np.conj(f), 2 * n, axis=1)[:, :n] / n
+    var = acov[:, 0]
+    ok = var > 0
+    rho = acov / np.where(ok, var, 1.0)[:, None]
+    npair = n // 2
+    pairs = rho[:, 0:2 * npair:2] + rho[:, 1:2 * npair:2]
+    positive = np.cumprod(pairs > 0, axis=1)               # 1 until the first non-positive pair
+    tau = -1.0 + 2.0 * (pairs * positive).sum(axis=1)
+    return np.where(ok, n / np.maximum(tau, 1.0 / n), 0.0)

@@ -149,3 +149,17 @@ def test_two_rank_gloo_sharding_gives_single_process_diagnostics(tmp_path, R11):
     rhat, ess = SH.rhat_ess(sums, 3, got["n_saved"], max_lag=4)
     rhat1, ess1 = SH.rhat_ess(want, 3, samples.shape[1], max_lag=4)
     assert np.allclose(rhat, rhat1, equal_nan=True) and np.allclose(ess, ess1)
+
+
+def test_ess_geyer_on_ar1_chains():
+    """ESS of an AR(1) chain with coefficient phi is n (1-phi)/(1+phi); i.i.d. draws give n."""
+    rs = np.random.RandomState(5)
+    m, n, phi = 8, 20000, 0.9
+    e = rs.standard_normal((m, n))
+    x = np.zeros((m, n))
+    for t in range(1, n):
+        x[:, t] = phi * x[:, t - 1] + e[:, t]
+    ess = SH.ess_geyer(x)
+    assert np.all(np.abs(ess / (n * (1 - phi) / (1 + phi)) - 1) < 0.25)
+    assert np.all(np.abs(SH.ess_geyer(e) / n - 1) < 0.1)
+    assert np.array_equal(SH.ess_geyer(np.ones((2, 50))), np.zeros(2))       # a chain that never moved
