@@ -254,6 +254,13 @@ __device__ __forceinline__ double4_t lds_row4(const double* Rneg, int L) {
     return *(const double4_t*)(Rneg + (size_t)L * 4);
 }
 
+/* element (row, lane) of a wave's tile: uniform base + 32-bit lane offset, the form the
+ * hardware addresses as SGPR base + VGPR offset + immediate (no 64-bit vector add) */
+__device__ __forceinline__ double ld_row(const double* base_u, int row, unsigned lane) {
+    const char* b = (const char*)(base_u + (size_t)row * MCMC_WAVE);
+    return *(const double*)(b + ((lane & (MCMC_WAVE - 1)) << 3));
+}
+
 /* ------------------------------------------------------- phase A building blocks ---- */
 /* One chunk = T consecutive lags Lc, Lc-1, ..., Lc-T+1 applied to the T days of the block.
  * History window: element q in [0, 2T-1) is W[q] for q < T and N[q-T] otherwise, holding
@@ -281,7 +288,7 @@ __device__ __forceinline__ void lag_chunk(double (&acc)[A_NPOS][T], double (&W)[
             acc[A_DEAD][t] = madd<FUSE>(nk, r[6], acc[A_DEAD][t]);
         }
         /* slot u of W is dead from here on: prefetch for the chunk after next */
-        W[u] = hn_next_u[u * MCMC_WAVE + lane];
+        W[u] = ld_row(hn_next_u, u, lane);
         r = rnext;
     }
 }
@@ -318,10 +325,95 @@ __device__ __forceinline__ void lag_chunk_e(double (&acc)[A_NPOS][T], double (&W
             acc[A_REC][t] = madd<FUSE>(nek, rn[1], acc[A_REC][t]);      /* covid.h:427 */
             acc[A_DEAD][t] = madd<FUSE>(nek, rn[2], acc[A_DEAD][t]);    /* covid.h:428 */
         }
-        W[u] = hn_next_u[u * MCMC_WAVE + lane];
-        EW[u] = he_next_u[u * MCMC_WAVE + lane];
+        W[u] = ld_row(hn_next_u, u, lane);
+        EW[u] = ld_row(he_next_u, u, lane);
         r = rnext;
         rn = rnnext;
+    }
+}
+
+
+/* ---------------------------------------------- rows 0..T-1 across the lanes (FUSE) ---- */
+/* The sequential part of a block (phase B and the tail) multiplies with the table rows of
+ * the lags 0..T-1 only.  With FMA contraction those 8 rows x 7 curves live ACROSS THE LANES
+ * of four VGPR pairs instead of being re-read from LDS (or parked in AccVGPRs) for every
+ * multiply-add: lane 8*h + c of each 16-lane row of pair g holds R[2g+h][c], and
+ * v_fmac_f64_dpp with row_newbcast broadcasts that lane as the multiplicand -- one
+ * instruction per multiply-add and the same fused operation as v_fmac_f64, bit for bit.
+ * The leading s_nop covers the two wait states a DPP source needs after a VALU write
+ * (the compiler may have just restored the pair from an AccVGPR; it cannot see into the
+ * asm).  All 64 lanes are active wherever these are used. */
+#ifndef MCMC_DPP_ROWS
+#define MCMC_DPP_ROWS 1
+#endif
+struct RowRegs {
+    double pos[4];      /* rows 0..7 of Rpos, two rows per pair                             */
+    double neg[2];      /* rows 0..7 of Rneg, four rows per pair: lane 4*(d&3)+c             */
+};
+__device__ __forceinline__ RowRegs load_row_regs(const LdsView& lds, unsigned lane) {
+    RowRegs R;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) R.pos[g] = lds.Rpos[(2 * g + ((lane >> 3) & 1)) * 8 + (lane & 7)];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) R.neg[h] = lds.Rneg[(4 * h + ((lane >> 2) & 3)) * 4 + (lane & 3)];
+    return R;
+}
+#define MCMC_DPP_FMAC(D, LANE) "v_fmac_f64_dpp " D ", %[row], %[nk] row_newbcast:" #LANE " row_mask:0xf bank_mask:0xf\n\t"
+/* acc[c][tt] += R[row][c] * nk for the seven curves; HALF = row & 1 */
+template <int T, int HALF>
+__device__ __forceinline__ void dpp_row7(double (&acc)[A_NPOS][T], int tt, double rowv, double nk) {
+    if constexpr (HALF == 0)
+        asm("s_nop 1\n\t" MCMC_DPP_FMAC("%0", 0) MCMC_DPP_FMAC("%1", 1) MCMC_DPP_FMAC("%2", 2) MCMC_DPP_FMAC("%3", 3)
+            MCMC_DPP_FMAC("%4", 4) MCMC_DPP_FMAC("%5", 5) MCMC_DPP_FMAC("%6", 6)
+            : "+v"(acc[0][tt]), "+v"(acc[1][tt]), "+v"(acc[2][tt]), "+v"(acc[3][tt]), "+v"(acc[4][tt]),
+              "+v"(acc[5][tt]), "+v"(acc[6][tt])
+            : [row] "v"(rowv), [nk] "v"(nk));
+    else
+        asm("s_nop 1\n\t" MCMC_DPP_FMAC("%0", 8) MCMC_DPP_FMAC("%1", 9) MCMC_DPP_FMAC("%2", 10) MCMC_DPP_FMAC("%3", 11)
+            MCMC_DPP_FMAC("%4", 12) MCMC_DPP_FMAC("%5", 13) MCMC_DPP_FMAC("%6", 14)
+            : "+v"(acc[0][tt]), "+v"(acc[1][tt]), "+v"(acc[2][tt]), "+v"(acc[3][tt]), "+v"(acc[4][tt]),
+              "+v"(acc[5][tt]), "+v"(acc[6][tt])
+            : [row] "v"(rowv), [nk] "v"(nk));
+}
+/* the two rows of a pair applied to the destination days tt (even row) and tt+1 (odd row) */
+template <int T>
+__device__ __forceinline__ void dpp_row14(double (&acc)[A_NPOS][T], int tt, double rowv, double nk) {
+    asm("s_nop 1\n\t" MCMC_DPP_FMAC("%0", 0) MCMC_DPP_FMAC("%1", 1) MCMC_DPP_FMAC("%2", 2) MCMC_DPP_FMAC("%3", 3)
+        MCMC_DPP_FMAC("%4", 4) MCMC_DPP_FMAC("%5", 5) MCMC_DPP_FMAC("%6", 6)
+        MCMC_DPP_FMAC("%7", 8) MCMC_DPP_FMAC("%8", 9) MCMC_DPP_FMAC("%9", 10) MCMC_DPP_FMAC("%10", 11)
+        MCMC_DPP_FMAC("%11", 12) MCMC_DPP_FMAC("%12", 13) MCMC_DPP_FMAC("%13", 14)
+        : "+v"(acc[0][tt]), "+v"(acc[1][tt]), "+v"(acc[2][tt]), "+v"(acc[3][tt]), "+v"(acc[4][tt]),
+          "+v"(acc[5][tt]), "+v"(acc[6][tt]),
+          "+v"(acc[0][tt + 1]), "+v"(acc[1][tt + 1]), "+v"(acc[2][tt + 1]), "+v"(acc[3][tt + 1]), "+v"(acc[4][tt + 1]),
+          "+v"(acc[5][tt + 1]), "+v"(acc[6][tt + 1])
+        : [row] "v"(rowv), [nk] "v"(nk));
+}
+/* the capacity correction of one source day on destination day tt at lag d (covid.h:418,
+ * 426-428): dead += e, then the three negative projections with nek = -e; SLOT = d & 3 */
+template <int T, int SLOT>
+__device__ __forceinline__ void dpp_neg3(double (&acc)[A_NPOS][T], int tt, double negv, double ek, double nek) {
+    acc[A_DEAD][tt] = acc[A_DEAD][tt] + ek;
+#define MCMC_DPP_NEG(L0, L1, L2)                                                                                   \
+    asm("s_nop 1\n\t"                                                                                              \
+        "v_fmac_f64_dpp %0, %[row], %[nk] row_newbcast:" #L0 " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_fmac_f64_dpp %1, %[row], %[nk] row_newbcast:" #L1 " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_fmac_f64_dpp %2, %[row], %[nk] row_newbcast:" #L2 " row_mask:0xf bank_mask:0xf\n\t"                      \
+        : "+v"(acc[A_SER][tt]), "+v"(acc[A_REC][tt]), "+v"(acc[A_DEAD][tt])                                         \
+        : [row] "v"(negv), [nk] "v"(nek))
+    if constexpr (SLOT == 0) MCMC_DPP_NEG(0, 1, 2);
+    else if constexpr (SLOT == 1) MCMC_DPP_NEG(4, 5, 6);
+    else if constexpr (SLOT == 2) MCMC_DPP_NEG(8, 9, 10);
+    else MCMC_DPP_NEG(12, 13, 14);
+#undef MCMC_DPP_NEG
+}
+template <int T>
+__device__ __forceinline__ void dpp_neg3_at(double (&acc)[A_NPOS][T], int tt, int d, const RowRegs& RR, double ek, double nek) {
+    const double negv = RR.neg[d >> 2];
+    switch (d & 3) {
+        case 0: dpp_neg3<T, 0>(acc, tt, negv, ek, nek); break;
+        case 1: dpp_neg3<T, 1>(acc, tt, negv, ek, nek); break;
+        case 2: dpp_neg3<T, 2>(acc, tt, negv, ek, nek); break;
+        default: dpp_neg3<T, 3>(acc, tt, negv, ek, nek); break;
     }
 }
 
@@ -329,7 +421,26 @@ __device__ __forceinline__ void lag_chunk_e(double (&acc)[A_NPOS][T], double (&W
 template <int T, bool FUSE, bool WITH_E>
 __device__ __forceinline__ void lag_tail(double (&acc)[A_NPOS][T], const double (&W)[T],
                                          const double* Rpos, const double* Rneg, const double* he_k0_u,
-                                         unsigned lane) {
+                                         unsigned lane, const RowRegs& RR) {
+    if constexpr (FUSE && T == 8 && MCMC_DPP_ROWS) {
+        double ek[WITH_E ? T - 1 : 1];
+        if constexpr (WITH_E) {
+#pragma unroll
+            for (int q = 0; q < T - 1; ++q) ek[q] = he_k0_u[q * MCMC_WAVE + lane];
+        }
+#pragma unroll
+        for (int v = 1; v < T; ++v) {
+            const int L = T - v;
+#pragma unroll
+            for (int t = 0; t < L; ++t) {
+                const double nk = W[t + v - 1];
+                if (L & 1) dpp_row7<T, 1>(acc, t, RR.pos[L >> 1], nk);
+                else dpp_row7<T, 0>(acc, t, RR.pos[L >> 1], nk);
+                if constexpr (WITH_E) dpp_neg3_at<T>(acc, t, L, RR, ek[t + v - 1], -ek[t + v - 1]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int v = 1; v < T; ++v) {
         const int L = T - v;
@@ -427,8 +538,6 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
             WA[q] = hbase[q * MCMC_WAVE + lane];
             WB[q] = hbase[(q + T) * MCMC_WAVE + lane];
         }
-        int segCur = -2;
-        double pcfCur = 1.0;
         pc.stamp(PH_SETUP);
         double* ds_u = B.d1s_u + (shift == 1 ? 0 : M.nData * MCMC_WAVE);
 
@@ -525,17 +634,28 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
             }
             /* what phase B needs from memory, requested before the tail's 7*T*(T-1)/2
              * multiply-adds: the behaviour values of the block's days */
+            /* rows 0..T-1 across the lanes, for the tail and phase B of this block (re-read per
+             * block: six LDS reads, and the registers stay free during the lag loops) */
+            RowRegs RR;
+            if constexpr (FUSE && T == 8 && MCMC_DPP_ROWS) RR = load_row_regs(lds, lane);
+            double pcfv[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const int bi = min(max(j0 + t - md, 0), M.nB - 1);
                 beh[t] = B.x_u[bi * MCMC_WAVE + lane];
+                /* piecewise-constant factor of the day's breakpoint interval (covid.h:432-444).
+                 * Loaded here and not inside phase B: a load there makes every day wait for
+                 * ALL outstanding vector memory operations, the history stores included. */
+                const int sg = __builtin_amdgcn_readfirstlane(lds.seg[j0 + t]);
+                const double dv = xdisc_u[max(sg, 0) * MCMC_WAVE + lane];
+                pcfv[t] = sg >= 0 ? dv : 1.0;
             }
             pc.stamp(PH_CHUNKS);
             /* the tail reads source days [j0-T+1, j0-1] */
             if (anyE && j0 - T + 1 <= keHi && j0 - 1 >= keLo)
-                lag_tail<T, FUSE, true>(acc, WA, lds.Rpos, lds.Rneg, ebase + b * T * MCMC_WAVE, lane);
+                lag_tail<T, FUSE, true>(acc, WA, lds.Rpos, lds.Rneg, ebase + b * T * MCMC_WAVE, lane, RR);
             else
-                lag_tail<T, FUSE, false>(acc, WA, lds.Rpos, lds.Rneg, nullptr, lane);
+                lag_tail<T, FUSE, false>(acc, WA, lds.Rpos, lds.Rneg, nullptr, lane, RR);
             pc.stamp(PH_TAIL);
             /* the window registers are free now: request the first window of the NEXT block
              * before the sequential phase B, unless this block is about to write into it
@@ -552,17 +672,31 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const int i = j0 + t;
-                /* today's new infections into today and the rest of the block (covid.h:403-410) */
+                /* today's new infections into today and the rest of the block (covid.h:403-410).
+                 * The rows 0..T-1 are re-read from LDS every day (the opaque zero keeps the
+                 * compiler from parking all of them in AccVGPRs, which costs two register
+                 * moves per multiply-add) */
+                if constexpr (FUSE && T == 8 && MCMC_DPP_ROWS) {
 #pragma unroll
-                for (int tt = t; tt < T; ++tt) {
-                    const double8_t r0 = lds_row8(lds.Rpos, tt - t);
-                    acc[A_MI][tt] = madd<FUSE>(ncur, r0[0], acc[A_MI][tt]);
-                    acc[A_HI][tt] = madd<FUSE>(ncur, r0[1], acc[A_HI][tt]);
-                    acc[A_INC][tt] = madd<FUSE>(ncur, r0[2], acc[A_INC][tt]);
-                    acc[A_MILD][tt] = madd<FUSE>(ncur, r0[3], acc[A_MILD][tt]);
-                    acc[A_SER][tt] = madd<FUSE>(ncur, r0[4], acc[A_SER][tt]);
-                    acc[A_REC][tt] = madd<FUSE>(ncur, r0[5], acc[A_REC][tt]);
-                    acc[A_DEAD][tt] = madd<FUSE>(ncur, r0[6], acc[A_DEAD][tt]);
+                    for (int d = 0; d < T - t; d += 2) {
+                        if (d + 1 < T - t) dpp_row14<T>(acc, t + d, RR.pos[d >> 1], ncur);
+                        else dpp_row7<T, 0>(acc, t + d, RR.pos[d >> 1], ncur);
+                    }
+                } else {
+                    int rowOff = 0;
+                    asm volatile("" : "+s"(rowOff));
+                    const double* rpB = lds.Rpos + rowOff;
+#pragma unroll
+                    for (int tt = t; tt < T; ++tt) {
+                        const double8_t r0 = lds_row8(rpB, tt - t);
+                        acc[A_MI][tt] = madd<FUSE>(ncur, r0[0], acc[A_MI][tt]);
+                        acc[A_HI][tt] = madd<FUSE>(ncur, r0[1], acc[A_HI][tt]);
+                        acc[A_INC][tt] = madd<FUSE>(ncur, r0[2], acc[A_INC][tt]);
+                        acc[A_MILD][tt] = madd<FUSE>(ncur, r0[3], acc[A_MILD][tt]);
+                        acc[A_SER][tt] = madd<FUSE>(ncur, r0[4], acc[A_SER][tt]);
+                        acc[A_REC][tt] = madd<FUSE>(ncur, r0[5], acc[A_REC][tt]);
+                        acc[A_DEAD][tt] = madd<FUSE>(ncur, r0[6], acc[A_DEAD][tt]);
+                    }
                 }
                 /* hospital capacity (covid.h:413-429) */
                 const double overCapacity = acc[A_SER][t] * M.probICU - lds.capacity[i];
@@ -574,23 +708,22 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                     keLo = min(keLo, i);
                     keHi = max(keHi, i);
                     const double ne = -e;
+                    if constexpr (FUSE && T == 8 && MCMC_DPP_ROWS) {
 #pragma unroll
-                    for (int tt = t; tt < T; ++tt) {
-                        const double4_t rn = lds_row4(lds.Rneg, tt - t);
-                        acc[A_DEAD][tt] = acc[A_DEAD][tt] + e;
-                        acc[A_SER][tt] = madd<FUSE>(ne, rn[0], acc[A_SER][tt]);
-                        acc[A_REC][tt] = madd<FUSE>(ne, rn[1], acc[A_REC][tt]);
-                        acc[A_DEAD][tt] = madd<FUSE>(ne, rn[2], acc[A_DEAD][tt]);
+                        for (int tt = t; tt < T; ++tt) dpp_neg3_at<T>(acc, tt, tt - t, RR, e, ne);
+                    } else {
+#pragma unroll
+                        for (int tt = t; tt < T; ++tt) {
+                            const double4_t rn = lds_row4(lds.Rneg, tt - t);
+                            acc[A_DEAD][tt] = acc[A_DEAD][tt] + e;
+                            acc[A_SER][tt] = madd<FUSE>(ne, rn[0], acc[A_SER][tt]);
+                            acc[A_REC][tt] = madd<FUSE>(ne, rn[1], acc[A_REC][tt]);
+                            acc[A_DEAD][tt] = madd<FUSE>(ne, rn[2], acc[A_DEAD][tt]);
+                        }
                     }
                 }
                 /* piecewise-constant factor and behaviour (covid.h:432-454) */
-                const int sg = __builtin_amdgcn_readfirstlane(lds.seg[i]);
-                if (sg != segCur) {                                 /* a few times per pass */
-                    segCur = sg;
-                    pcfCur = 1.0;
-                    if (sg >= 0) pcfCur = xdisc_u[sg * MCMC_WAVE + lane];
-                }
-                const double pcf = pcfCur;
+                const double pcf = pcfv[t];
                 double smoothbehavior = 1.0;
                 if (i >= md) smoothbehavior = pcf * beh[t];
                 const double totalBehavior = pcf * smoothbehavior;
