@@ -329,6 +329,11 @@ __device__ __forceinline__ void lag_chunk_e(double (&acc)[A_NPOS][T], double (&W
         EW[u] = ld_row(he_next_u, u, lane);
         r = rnext;
         rn = rnnext;
+        /* keep every lag step's prefetch where it is: left alone, the scheduler sometimes
+         * gathers the loads at the end of the unrolled body, right before their use */
+#if MCMC_E_SCHEDBAR
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 }
 
@@ -343,6 +348,24 @@ __device__ __forceinline__ void lag_chunk_e(double (&acc)[A_NPOS][T], double (&W
  * The leading s_nop covers the two wait states a DPP source needs after a VALU write
  * (the compiler may have just restored the pair from an AccVGPR; it cannot see into the
  * asm).  All 64 lanes are active wherever these are used. */
+#ifndef MCMC_LL_BATCH
+#define MCMC_LL_BATCH 16     /* rows per memory round trip in the likelihood pass, ...  */
+#endif
+#ifndef MCMC_PROP_BATCH
+#define MCMC_PROP_BATCH 16   /* ... the proposal loop ...                              */
+#endif
+#ifndef MCMC_ACC_BATCH
+#define MCMC_ACC_BATCH 32    /* ... and the accept copy (a lone wave has 512 registers) */
+#endif
+#ifndef MCMC_E_DRAIN
+#define MCMC_E_DRAIN 1
+#endif
+#ifndef MCMC_LANE_LAUNDER
+#define MCMC_LANE_LAUNDER 1
+#endif
+#ifndef MCMC_E_SCHEDBAR
+#define MCMC_E_SCHEDBAR 1
+#endif
 #ifndef MCMC_DPP_ROWS
 #define MCMC_DPP_ROWS 1
 #endif
@@ -587,16 +610,25 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
             for (int seg = 0; seg < 3; ++seg) {
                 int nch = (seg == 0) ? cLo - c0 : (seg == 1) ? cHi - cLo + 1 : b - 1 - cHi;
                 pc.count(seg == 1 ? PH_NCHUNK_E : PH_NCHUNK, nch);
+                /* The lane index the lag loops address with is re-defined here, as an opaque
+                 * copy.  Otherwise the compiler may reload its (spilled) 64-bit lane offset
+                 * just ahead of a loop; a load still pending at the loop header makes the
+                 * wait-count pass put a full vmcnt(0) INSIDE the loop, which drains the
+                 * window prefetch every iteration. */
+                unsigned laneL = lane;
+#if MCMC_LANE_LAUNDER
+                asm volatile("" : "+v"(laneL));
+#endif
                 if (seg != 1) {
 #pragma unroll 1
                     for (; nch >= 2; nch -= 2) {
-                        lag_chunk<T, FUSE>(acc, WA, WB, r, lds.Rpos, Lc, hnx, lane);
-                        lag_chunk<T, FUSE>(acc, WB, WA, r, lds.Rpos, Lc - T, hnx + T * MCMC_WAVE, lane);
+                        lag_chunk<T, FUSE>(acc, WA, WB, r, lds.Rpos, Lc, hnx, laneL);
+                        lag_chunk<T, FUSE>(acc, WB, WA, r, lds.Rpos, Lc - T, hnx + T * MCMC_WAVE, laneL);
                         hnx += 2 * T * MCMC_WAVE;
                         Lc -= 2 * T;
                     }
                     if (nch > 0) {
-                        lag_chunk<T, FUSE>(acc, WA, WB, r, lds.Rpos, Lc, hnx, lane);
+                        lag_chunk<T, FUSE>(acc, WA, WB, r, lds.Rpos, Lc, hnx, laneL);
 #pragma unroll
                         for (int q = 0; q < T; ++q) { const double tmp = WA[q]; WA[q] = WB[q]; WB[q] = tmp; }
                         hnx += T * MCMC_WAVE;
@@ -608,22 +640,28 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                     double EA[T], EB[T];
 #pragma unroll
                     for (int q = 0; q < T; ++q) {
-                        EA[q] = ek0[q * MCMC_WAVE + lane];
-                        EB[q] = ek0[(q + T) * MCMC_WAVE + lane];
+                        EA[q] = ek0[q * MCMC_WAVE + laneL];
+                        EB[q] = ek0[(q + T) * MCMC_WAVE + laneL];
                     }
                     const double* ekx = ek0 + 2 * T * MCMC_WAVE;
                     double4_t rn = lds_row4(lds.Rneg, Lc);
+                    /* the e-window just requested is needed by the first chunk anyway; with it
+                     * still in flight at the loop header the wait counts inside the loop come
+                     * out far too tight for the steady state */
+#if MCMC_E_DRAIN
+                    if (nch >= 2) __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0) */
+#endif
 #pragma unroll 1
                     for (; nch >= 2; nch -= 2) {
-                        lag_chunk_e<T, FUSE>(acc, WA, WB, EA, EB, r, rn, lds.Rpos, lds.Rneg, Lc, hnx, ekx, lane);
+                        lag_chunk_e<T, FUSE>(acc, WA, WB, EA, EB, r, rn, lds.Rpos, lds.Rneg, Lc, hnx, ekx, laneL);
                         lag_chunk_e<T, FUSE>(acc, WB, WA, EB, EA, r, rn, lds.Rpos, lds.Rneg, Lc - T,
-                                             hnx + T * MCMC_WAVE, ekx + T * MCMC_WAVE, lane);
+                                             hnx + T * MCMC_WAVE, ekx + T * MCMC_WAVE, laneL);
                         hnx += 2 * T * MCMC_WAVE;
                         ekx += 2 * T * MCMC_WAVE;
                         Lc -= 2 * T;
                     }
                     if (nch > 0) {
-                        lag_chunk_e<T, FUSE>(acc, WA, WB, EA, EB, r, rn, lds.Rpos, lds.Rneg, Lc, hnx, ekx, lane);
+                        lag_chunk_e<T, FUSE>(acc, WA, WB, EA, EB, r, rn, lds.Rpos, lds.Rneg, Lc, hnx, ekx, laneL);
 #pragma unroll
                         for (int q = 0; q < T; ++q) { const double tmp = WA[q]; WA[q] = WB[q]; WB[q] = tmp; }
                         hnx += T * MCMC_WAVE;
@@ -772,7 +810,7 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
              * term is formed, so one memory round trip is paid per eight days, not per day */
             const double* d1_u = B.d1s_u;
             const double* d0_u = B.d1s_u + M.nData * MCMC_WAVE;
-            constexpr int LB = 8;
+            constexpr int LB = MCMC_LL_BATCH;
 #pragma unroll 1
             for (int d0 = 0; d0 < M.nData; d0 += LB) {
                 double dv[LB];
@@ -904,7 +942,7 @@ __device__ inline bool propose(const DevModel& M, Pcg32& rnd, const double* __re
         const double dx = M.smoothL / (double)n;
         double loglike = 0;
         double fm = 0, f0 = 0;
-        constexpr int PB = 4;                /* loads of a trip are requested together */
+        constexpr int PB = MCMC_PROP_BATCH;   /* loads of a trip are requested together */
 #pragma unroll 1
         for (int i0 = 0; i0 < n; i0 += PB) {
             double vv[PB];
@@ -1074,7 +1112,7 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
         const double u = (double)rnd.next_float();
         const bool accept = u < 1.0 * mcmc_exp(delta);              /* mcmc.h:776 */
         if (__any(accept)) {                                        /* State::accept, mcmc.h:653-661 */
-            constexpr int AB = 8;
+            constexpr int AB = MCMC_ACC_BATCH;
 #pragma unroll 1
             for (int k0 = 0; k0 < S.dim; k0 += AB) {
                 double vv[AB];
