@@ -102,6 +102,30 @@ def test_eval_delay_edge_cases(R11, R10):
     s.close()
 
 
+def test_long_horizon_beyond_the_trajectory_table(R11, R10):
+    """size = 40 + 60 + 520 = 620 days > traj.nDays = 500: lags past the table contribute
+    nothing (the `d < nDays` cut of project(), covid.h:378), whole chunks of them are skipped
+    and the lag window starts later -- eval, derive and MH steps against the oracle."""
+    cfg = make_cfg(520, R11, initial_beta_mild=0.5, initial_beta_high=1.5)
+    assert cfg["size"] == 620
+    m = O.Model(cfg, R11)
+    xs = perturbed(cfg, 66, 0.05)
+    s = H.CovidSampler(cfg, R10)
+    ll = s.eval(xs)
+    ref = np.array([[m.eval(x), m.prior(x)] for x in xs])
+    assert np.array_equal(ll, ref) and np.all(np.isfinite(ll))
+    cur = s.derive(xs[:3])
+    refc = np.array([m.eval(x, curves=True)[1] for x in xs[:3]])
+    assert np.array_equal(cur, refc)
+    tgt = O.make_target("temp", 1.0)
+    s.set_chains(xs)
+    s.step(5, 1.0, True)
+    st = _state(s)
+    for c in (0, 63, 65):
+        _assert_chain_equal(_oracle_after_steps(m, tgt, c + 1, xs[c], 5), st, c)
+    s.close()
+
+
 def test_eval_nonfinite_parameters_do_not_fault(R11, R10):
     """NaN/Inf parameters (the reference rejects such initial states, mcmc.h:1334,1365): the
     kernel must stay in bounds and report a non-finite or oracle-equal loglike."""
