@@ -117,6 +117,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ess-chains", type=int, default=4096, help="chains of the ESS leg (0: skip it)")
     ap.add_argument("--ess-steps", type=int, default=2000)
+    # BASELINE.json configs[3] (extension): ladders of K temperatures, whole ladders per GPU
+    ap.add_argument("--ladder", type=int, default=0, help="temperatures per ladder (0: no tempering)")
+    ap.add_argument("--ladder-tmax", type=float, default=16.0)
+    ap.add_argument("--swap-every", type=int, default=8, help="MH steps between exchange rounds")
     # rehearsal knobs: several ranks on ONE card need the gloo backend and a fixed device
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--device", type=int, default=None, help="HIP ordinal for every rank (default: LOCAL_RANK)")
@@ -150,6 +154,9 @@ def main():
 
     if args.adjust > 0:
         s.run(0, 0, args.adjust, 1000000)                # step-size adaptation only, nothing recorded
+    if args.ladder:
+        temps = np.geomspace(1.0, args.ladder_tmax, args.ladder)
+        s.set_ladder(temps, swap_seed=1, first_ladder=rank * (n_chains // args.ladder))
     s.step(args.warmup, 1.0, True)
     n_keep = max(256, min(args.ess_chains, n_chains))
     cpu_start = (s.params()[:n_keep].copy(), s.stepsizes()[:n_keep].copy()) if rank == 0 else None
@@ -157,7 +164,12 @@ def main():
     t_before = s.last_timing()
     sync()
     t0 = time.perf_counter()
-    s.step(args.steps, 1.0, True)                        # the library syncs its stream per launch
+    if args.ladder:
+        s.run_tempered(args.steps // args.swap_every, args.swap_every)
+        if args.steps % args.swap_every:
+            s.step(args.steps % args.swap_every, 1.0, True)
+    else:
+        s.step(args.steps, 1.0, True)                    # the library syncs its stream per launch
     sync()
     dt = time.perf_counter() - t0
     t_after = s.last_timing()
@@ -193,6 +205,8 @@ def main():
                        "chains_per_gpu": n_chains, "n_data": N_DATA, "dim": cfg["dim"],
                        "size": cfg["size"], "fp_contract": "fma" if args.contract else "strict",
                        "adjust_iterations_before_timing": args.adjust,
+                       **({"ladder": {"temperatures": args.ladder, "t_max": args.ladder_tmax,
+                                      "swap_every": args.swap_every}} if args.ladder else {}),
                        "parallelism": f"chain-shard x{world}"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP64_VECTOR_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VECTOR_TFLOPS,
@@ -206,7 +220,7 @@ def main():
             cb = cpu_baseline(cfg, R, cpu_start[0], cpu_start[1], args.contract)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = value / cb["value"]
-        if world == 1 and args.ess_chains > 0:
+        if world == 1 and args.ess_chains > 0 and not args.ladder:
             ne = min(args.ess_chains, n_chains)
             e = ess_leg(cfg, R, device, args.contract, cpu_start[0][:ne], cpu_start[1][:ne], first_id, args.ess_steps, 5)
             worst = min(e["ess_per_step"].values())

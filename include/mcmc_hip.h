@@ -180,6 +180,26 @@ int mcmc_hip_last_timing(mcmc_hip_ctx* ctx, double* adjust_s, double* sampling_s
  * summed over chains: each pair is one multiply-add per compartment (covid.h:384). */
 int mcmc_hip_pair_count(mcmc_hip_ctx* ctx, double* pairs_out, int32_t reset);
 
+/* --- tempering ladder with swap exchange (EXTENSION: BASELINE.json configs[3]; the reference has
+ * no replica exchange -- its TempTarget, mcmc.h:797-808, only fixes one temperature per run).
+ * After set_chains, the chains [L*n_temps, (L+1)*n_temps) form ladder L and chain i starts on
+ * rung i % n_temps, i.e. under TempTarget(temps[rung]): every step's beta is multiplied by
+ * 1/temps[rung].  mcmc_hip_swap does one exchange round between the rungs (r, r+1),
+ * r = parity, parity+2, ...: accept iff double(u) < exp((beta_r - beta_{r+1}) (l_{r+1} - l_r)),
+ * l = State::loglikelihood (mcmc.h:612-618), u = nextFloat() of pcg32(swap_seed, first_ladder+L),
+ * one draw per pair.  Accepted pairs exchange their temperatures, not their states.  Ladders are
+ * independent, so several GPUs take whole ladders each (first_ladder = the shard's first ladder
+ * id) and no exchange crosses a device.  n_temps = 0 removes the ladder. */
+int mcmc_hip_set_ladder(mcmc_hip_ctx* ctx, int32_t n_temps, const double* temps, uint64_t swap_seed,
+                        uint64_t first_ladder);
+int mcmc_hip_swap(mcmc_hip_ctx* ctx, int32_t parity);
+/* n_rounds x (steps_per_round Target::step calls with a random subspace, then one swap round of
+ * alternating parity 0,1,0,...) */
+int mcmc_hip_run_tempered(mcmc_hip_ctx* ctx, int32_t n_rounds, int32_t steps_per_round);
+int mcmc_hip_get_rungs(mcmc_hip_ctx* ctx, int32_t* out /*[n_chains]*/);
+/* per rung pair r = 0..n_temps-2: accepted and proposed exchanges since set_ladder */
+int mcmc_hip_get_swap_counts(mcmc_hip_ctx* ctx, int64_t* accepted, int64_t* proposed);
+
 /* --- toy targets (test.h:14-136): MyLike1 (3-D Gaussian, the CLI run of test.cpp:27-40) and
  * FourGaussians(difficulty), each as the single likelihood of a State, under
  * MetropolisChain::run (mcmc.h:1005-1138) with Target / TempTarget / CoolingTarget.  One chain

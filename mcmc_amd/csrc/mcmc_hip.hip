@@ -90,6 +90,14 @@ struct mcmc_hip_ctx {
     DevBuf<uint64_t> dRng;
     DevBuf<int> dNAccept;
     DevBuf<unsigned long long> dPairs;
+    /* tempering ladder (extension) */
+    int ladderK = 0;
+    long long nLadders = 0;
+    DevBuf<double> dLadderBeta, dChainBeta;
+    DevBuf<int> dChainAt, dRungOf;
+    DevBuf<uint64_t> dSwapRng;
+    DevBuf<unsigned long long> dSwapAcc;
+    unsigned long long swapRounds[2] = {0, 0};
     /* scratch */
     DevBuf<double> dBetas;
     DevBuf<int> dFlags;
@@ -507,6 +515,7 @@ int mcmc_hip_set_chains(mcmc_hip_ctx* c, int64_t n_chains, const double* params,
     S.params = c->dParams.p; S.prop = c->dParams.p + (size_t)dim * nP; S.ll = c->dLL.p; S.stepsize = c->dStepsize.p;
     S.rng = c->dRng.p; S.nAccept = c->dNAccept.p; S.pairs = c->dPairs.p; S.mean = c->dMean.p;
     S.recLL = nullptr; S.recSamples = nullptr; S.nChains = n; S.dim = dim;
+    S.chainBeta = nullptr; c->ladderK = 0; c->nLadders = 0;         /* a new set of chains has no ladder */
     if (int r = alloc_work(c, nP)) return r;
 
     /* upload chain-major params and transpose to SoA on the device */
@@ -548,6 +557,92 @@ int mcmc_hip_step(mcmc_hip_ctx* c, int32_t n_steps, double beta, int32_t random_
     std::vector<double> betas(n_steps, beta);
     std::vector<int> flags(n_steps, random_subspace ? SF_RANDOM : 0);
     return run_schedule(c, betas, flags, 0, (size_t)n_steps, MCMC_STEPS_PER_LAUNCH, nullptr);
+}
+
+/* ---- tempering ladder (extension) ---- */
+int mcmc_hip_set_ladder(mcmc_hip_ctx* c, int32_t n_temps, const double* temps, uint64_t swap_seed, uint64_t first_ladder) {
+    if (int r = check_ctx(c)) return r;
+    if (!c->haveChains) return fail(MCMC_HIP_ESTATE, "set_ladder: call set_chains first");
+    if (n_temps == 0) { c->S.chainBeta = nullptr; c->ladderK = 0; c->nLadders = 0; return 0; }
+    if (n_temps < 2 || !temps) return fail(MCMC_HIP_EINVAL, "set_ladder: need n_temps >= 2 and temps");
+    if (c->nChains % n_temps != 0) return fail(MCMC_HIP_EINVAL, "set_ladder: n_chains must be a multiple of n_temps");
+    for (int r = 0; r < n_temps; ++r)
+        if (!(temps[r] > 0) || !std::isfinite(temps[r])) return fail(MCMC_HIP_EINVAL, "set_ladder: temperatures must be positive and finite");
+    HIP_TRY(hipSetDevice(c->device));
+    const int K = n_temps;
+    const long long n = c->nChains, nP = c->nP, nL = n / K;
+    std::vector<double> lb(K), cb(nP, 1.0);
+    for (int r = 0; r < K; ++r) lb[r] = 1 / temps[r];                /* TempTarget: bet = 1/T, mcmc.h:797-808 */
+    std::vector<int> at(n), rung(nP, 0);
+    std::vector<uint64_t> rng(2 * nL);
+    for (long long i = 0; i < n; ++i) { at[i] = (int)i; rung[i] = (int)(i % K); cb[i] = lb[i % K]; }
+    for (long long L = 0; L < nL; ++L) pcg32_seed(rng[2 * L], rng[2 * L + 1], swap_seed, first_ladder + (uint64_t)L);
+    if (int r = c->dLadderBeta.alloc(K)) return r;
+    if (int r = c->dChainBeta.alloc(nP)) return r;
+    if (int r = c->dChainAt.alloc(n)) return r;
+    if (int r = c->dRungOf.alloc(nP)) return r;
+    if (int r = c->dSwapRng.alloc(2 * nL)) return r;
+    if (int r = c->dSwapAcc.alloc(K)) return r;
+    HIP_TRY(hipMemcpyAsync(c->dLadderBeta.p, lb.data(), K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->dChainBeta.p, cb.data(), nP * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->dChainAt.p, at.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->dRungOf.p, rung.data(), nP * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->dSwapRng.p, rng.data(), 2 * nL * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->dSwapAcc.p, 0, K * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->S.chainBeta = c->dChainBeta.p;
+    c->ladderK = K; c->nLadders = nL;
+    c->swapRounds[0] = c->swapRounds[1] = 0;
+    return 0;
+}
+
+int mcmc_hip_swap(mcmc_hip_ctx* c, int32_t parity) {
+    if (int r = check_ctx(c)) return r;
+    if (!c->haveChains || c->ladderK < 2) return fail(MCMC_HIP_ESTATE, "swap: call set_ladder first");
+    if (parity != 0 && parity != 1) return fail(MCMC_HIP_EINVAL, "swap: parity must be 0 or 1");
+    HIP_TRY(hipSetDevice(c->device));
+    const unsigned grid = (unsigned)((c->nLadders + 255) / 256);
+    hipLaunchKernelGGL(ladder_swap_kernel, dim3(grid), dim3(256), 0, c->stream, c->S, c->M.hasPrior, c->ladderK, c->nLadders,
+                       (const double*)c->dLadderBeta.p, c->dChainAt.p, c->dRungOf.p, c->dSwapRng.p, c->dChainBeta.p,
+                       (int)parity, c->dSwapAcc.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->swapRounds[parity] += 1;
+    return 0;
+}
+
+int mcmc_hip_run_tempered(mcmc_hip_ctx* c, int32_t n_rounds, int32_t steps_per_round) {
+    if (int r = check_ctx(c)) return r;
+    if (!c->haveChains || c->ladderK < 2) return fail(MCMC_HIP_ESTATE, "run_tempered: call set_ladder first");
+    if (n_rounds < 0 || steps_per_round < 0) return fail(MCMC_HIP_EINVAL, "run_tempered: negative count");
+    for (int k = 0; k < n_rounds; ++k) {
+        if (int r = mcmc_hip_step(c, steps_per_round, 1.0, 1)) return r;
+        if (int r = mcmc_hip_swap(c, k & 1)) return r;
+    }
+    return 0;
+}
+
+int mcmc_hip_get_rungs(mcmc_hip_ctx* c, int32_t* out) {
+    if (int r = check_ctx(c)) return r;
+    if (!c->haveChains || c->ladderK < 2) return fail(MCMC_HIP_ESTATE, "get_rungs: call set_ladder first");
+    if (!out) return fail(MCMC_HIP_EINVAL, "null output buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy(out, c->dRungOf.p, c->nChains * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mcmc_hip_get_swap_counts(mcmc_hip_ctx* c, int64_t* accepted, int64_t* proposed) {
+    if (int r = check_ctx(c)) return r;
+    if (!c->haveChains || c->ladderK < 2) return fail(MCMC_HIP_ESTATE, "get_swap_counts: call set_ladder first");
+    if (!accepted || !proposed) return fail(MCMC_HIP_EINVAL, "null output buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<unsigned long long> h(c->ladderK);
+    HIP_TRY(hipMemcpy(h.data(), c->dSwapAcc.p, c->ladderK * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int r = 0; r + 1 < c->ladderK; ++r) {
+        accepted[r] = (int64_t)h[r];
+        proposed[r] = (int64_t)(c->swapRounds[r & 1] * (unsigned long long)c->nLadders);
+    }
+    return 0;
 }
 
 int mcmc_hip_run(mcmc_hip_ctx* c, int32_t nSamples, int32_t nBurnin, int32_t nAdjust, int32_t thinning,

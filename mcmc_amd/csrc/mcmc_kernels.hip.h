@@ -997,6 +997,7 @@ struct ChainState {
     double* mean;                 /* [nTiles][dim][64] or null                           */
     double* recLL;                /* [nSavedCap][nTiles][64]                             */
     double* recSamples;           /* [nSavedCap][nTiles][dim][64] or null                */
+    const double* chainBeta;      /* [nTiles][64] inverse temperature of the chain's rung, or null */
     long long nChains;
     int nTiles;
     int dim;
@@ -1061,11 +1062,13 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
     int slot = slot0;
     PhaseClock pc;
     pc.start();
+    /* tempering ladder (extension): the chain's rung multiplies the target's beta */
+    const double rungBeta = S.chainBeta ? S.chainBeta[flat] : 1.0;
 
 #pragma unroll 1
     for (int g = 0; g < n_steps; ++g) {
         const int fl = flags[g];
-        const double beta = betas[g];
+        const double beta = betas[g] * rungBeta;
 
         if (fl & SF_RESET_ACC) nAccept = 0;                         /* mcmc.h:1032,1090 */
         if (fl & SF_RECORD) {                                       /* mcmc.h:1037-1062 */
@@ -1234,6 +1237,48 @@ __global__ __launch_bounds__(MCMC_WAVE) void diagnostics_kernel(DevModel M, Chai
             atomicAdd(&out[5 + 2 * k], sx2);
         }
     }
+}
+
+/* ------------------------------------------------------------- tempering ladder ---- */
+/* Replica exchange (EXTENSION, BASELINE configs[3]; the reference has no such step).  The
+ * chains [L*K, (L+1)*K) form ladder L; chainAt[L][r] is the chain sitting on rung r, whose
+ * inverse temperature is ladderBeta[r].  One round proposes the exchange of the rungs
+ * (r, r+1) for r = parity, parity+2, ...: with l = State::loglikelihood (mcmc.h:612-618)
+ *     accept  iff  double(u) < exp((beta_r - beta_{r+1}) * (l_{r+1} - l_r)),
+ * u = nextFloat() of the ladder's own stream pcg32(swap_seed, ladder id), one draw per pair
+ * whether accepted or not.  Accepting swaps the TEMPERATURES of the two chains (16 bytes),
+ * not their states.  One thread per ladder. */
+__global__ __launch_bounds__(256) void ladder_swap_kernel(ChainState S, int hasPrior, int K, long long nLadders,
+                                                          const double* __restrict__ ladderBeta,
+                                                          int* __restrict__ chainAt, int* __restrict__ rungOf,
+                                                          uint64_t* __restrict__ swapRng, double* __restrict__ chainBeta,
+                                                          int parity, unsigned long long* __restrict__ nAccepted) {
+    const long long L = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >= nLadders) return;
+    Pcg32 rnd;
+    rnd.state = swapRng[2 * L];
+    rnd.inc = swapRng[2 * L + 1];
+    for (int r = parity; r + 1 < K; r += 2) {
+        const int a = chainAt[L * K + r], b = chainAt[L * K + r + 1];
+        const size_t ia = ((size_t)(a / MCMC_WAVE) * 2) * MCMC_WAVE + (size_t)(a % MCMC_WAVE);
+        const size_t ib = ((size_t)(b / MCMC_WAVE) * 2) * MCMC_WAVE + (size_t)(b % MCMC_WAVE);
+        double la = 0, lb = 0;
+        la += S.ll[ia];
+        lb += S.ll[ib];
+        if (hasPrior) { la += S.ll[ia + MCMC_WAVE]; lb += S.ll[ib + MCMC_WAVE]; }
+        const double delta = (ladderBeta[r] - ladderBeta[r + 1]) * (lb - la);
+        const double u = (double)rnd.next_float();
+        if (u < mcmc_exp(delta)) {
+            chainAt[L * K + r] = b;
+            chainAt[L * K + r + 1] = a;
+            rungOf[a] = r + 1;
+            rungOf[b] = r;
+            chainBeta[a] = ladderBeta[r + 1];
+            chainBeta[b] = ladderBeta[r];
+            atomicAdd(&nAccepted[r], 1ULL);
+        }
+    }
+    swapRng[2 * L] = rnd.state;
 }
 
 /* ------------------------------------------------------------------ toy targets ---- */

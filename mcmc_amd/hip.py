@@ -28,7 +28,8 @@ SYMBOLS = [
     "mcmc_hip_get_accept_counts", "mcmc_hip_get_rng_state", "mcmc_hip_get_loglikes",
     "mcmc_hip_get_samples", "mcmc_hip_get_sample_all", "mcmc_hip_get_mean", "mcmc_hip_eval",
     "mcmc_hip_derive", "mcmc_hip_diagnostics", "mcmc_hip_last_timing", "mcmc_hip_pair_count",
-    "mcmc_hip_debug_phase_cycles", "mcmc_hip_toy_dim", "mcmc_hip_toy_n_out", "mcmc_hip_toy_eval", "mcmc_hip_toy_run",
+    "mcmc_hip_debug_phase_cycles", "mcmc_hip_set_ladder", "mcmc_hip_swap", "mcmc_hip_run_tempered",
+    "mcmc_hip_get_rungs", "mcmc_hip_get_swap_counts", "mcmc_hip_toy_dim", "mcmc_hip_toy_n_out", "mcmc_hip_toy_eval", "mcmc_hip_toy_run",
 ]
 
 
@@ -97,6 +98,11 @@ def lib():
     L.mcmc_hip_last_timing.argtypes = [vp, dp, dp, dp, C.POINTER(C.c_int64)]
     L.mcmc_hip_pair_count.argtypes = [vp, dp, C.c_int32]
     L.mcmc_hip_debug_phase_cycles.argtypes = [vp, dp, C.c_int32]
+    L.mcmc_hip_set_ladder.argtypes = [vp, C.c_int32, dp, C.c_uint64, C.c_uint64]
+    L.mcmc_hip_swap.argtypes = [vp, C.c_int32]
+    L.mcmc_hip_run_tempered.argtypes = [vp, C.c_int32, C.c_int32]
+    L.mcmc_hip_get_rungs.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.mcmc_hip_get_swap_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.mcmc_hip_toy_dim.argtypes = [C.c_int32]
     L.mcmc_hip_toy_n_out.argtypes = [C.c_int32]
     L.mcmc_hip_toy_eval.argtypes = [C.c_int, C.c_int32, C.c_double, C.c_int64, dp, dp]
@@ -231,6 +237,27 @@ class CovidSampler:
         _check(lib().mcmc_hip_run(self._h, n_samples, n_burnin, n_adjust, thinning,
                                   int(record_samples), int(compute_mean)))
         self.n_saved = lib().mcmc_hip_n_saved(n_samples, n_burnin, n_adjust, thinning)
+
+    # --- tempering ladder (extension, BASELINE configs[3]) ----------------------------------
+    def set_ladder(self, temps, swap_seed=1, first_ladder=0):
+        t = np.ascontiguousarray(temps, dtype=np.float64)
+        _check(lib().mcmc_hip_set_ladder(self._h, t.size, _dp(t), swap_seed, first_ladder))
+        self.n_temps = t.size
+
+    def swap(self, parity):
+        _check(lib().mcmc_hip_swap(self._h, parity))
+
+    def run_tempered(self, n_rounds, steps_per_round):
+        _check(lib().mcmc_hip_run_tempered(self._h, n_rounds, steps_per_round))
+
+    def rungs(self):
+        return self._get("get_rungs", (self.n_chains,), np.int32, C.c_int32)
+
+    def swap_counts(self):
+        a = np.zeros(self.n_temps - 1, dtype=np.int64); p = np.zeros(self.n_temps - 1, dtype=np.int64)
+        _check(lib().mcmc_hip_get_swap_counts(self._h, a.ctypes.data_as(C.POINTER(C.c_int64)),
+                                              p.ctypes.data_as(C.POINTER(C.c_int64))))
+        return a, p
 
     def step(self, n_steps, beta=1.0, random_subspace=True):
         _check(lib().mcmc_hip_step(self._h, n_steps, beta, int(random_subspace)))
