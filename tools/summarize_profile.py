@@ -34,7 +34,7 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.
         agg[k] += [x for _, x in v[-2:]]
 mean = {k: sum(v) / len(v) for k, v in agg.items()}
 with open(os.path.join(dst, f"{tag}_pmc_summary.txt"), "w") as o:
-    o.write("rocprofv3 --pmc passes (one run per pass) of `python3 bench.py --no-cpu-baseline --steps 16 --warmup 16`;\n"
+    o.write("rocprofv3 --pmc passes (one run per pass) of `python3 bench.py --no-cpu-baseline --ess-chains 0 --steps 16 --warmup 16`;\n"
             "mh_step_kernel, mean per launch over the last two launches (adapted regime; 16 MH steps x 65536 chains, 1024 waves)\n")
     o.write(trace_note)
     for k in sorted(mean):
