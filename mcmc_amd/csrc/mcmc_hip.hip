@@ -98,6 +98,9 @@ struct mcmc_hip_ctx {
     DevBuf<uint64_t> dSwapRng;
     DevBuf<unsigned long long> dSwapAcc;
     unsigned long long swapRounds[2] = {0, 0};
+    /* cooperative pair of waves per tile (MCMC_HIP_COOP=1) */
+    bool coop = false;
+    DevBuf<int> dCoopErr;
     /* scratch */
     DevBuf<double> dBetas;
     DevBuf<int> dFlags;
@@ -255,7 +258,33 @@ int run_eval_current(mcmc_hip_ctx* c) {
     return launch_chain_kernel(c, eval_kernel<MCMC_T, false>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
 }
 
+template <typename K>
+int launch_coop(mcmc_hip_ctx* c, K kernel, int nSteps, const double* dBetas, const int* dFlags, int slot0) {
+    const unsigned grid = (unsigned)((c->nTiles + MCMC_WAVES_PER_BLOCK - 1) / MCMC_WAVES_PER_BLOCK);
+    size_t shmem = coop_sync_offset(c->M, MCMC_T) + MCMC_COOP_SYNC_BYTES;
+    if (shmem > kLdsMax)
+        return fail(MCMC_HIP_EINVAL, "the series is too long for the LDS image (%zu B > %zu B)", shmem, kLdsMax);
+    if (shmem < kLdsSolo) shmem = kLdsSolo;            /* 8 waves per workgroup: one workgroup per CU */
+    if (!c->dCoopErr.p) {
+        if (int r = c->dCoopErr.alloc(1)) return r;
+        HIP_TRY(hipMemsetAsync(c->dCoopErr.p, 0, sizeof(int), c->stream));
+    }
+    HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(MCMC_COOP_BLOCK), shmem, c->stream, c->M, c->S, nSteps, dBetas, dFlags,
+                       slot0, c->dCoopErr.p);
+    HIP_TRY(hipGetLastError());
+    int h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, c->dCoopErr.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h != 0) return fail(MCMC_HIP_EHIP, "cooperative step kernel: a wave ran into the hand-over spin limit");
+    return 0;
+}
+
 int launch_steps(mcmc_hip_ctx* c, int nSteps, const double* dBetas, const int* dFlags, int slot0) {
+    if (c->coop) {
+        if (c->cfg.contract) return launch_coop(c, mh_step_coop_kernel<MCMC_T, true>, nSteps, dBetas, dFlags, slot0);
+        return launch_coop(c, mh_step_coop_kernel<MCMC_T, false>, nSteps, dBetas, dFlags, slot0);
+    }
     if (c->cfg.contract)
         return launch_chain_kernel(c, mh_step_kernel<MCMC_T, true>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0);
     return launch_chain_kernel(c, mh_step_kernel<MCMC_T, false>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0);
@@ -377,6 +406,7 @@ int mcmc_hip_create(const mcmc_covid_config* cfg, int device, mcmc_hip_ctx** out
     c->cfg.disc_days = c->discDays.data();
     c->cfg.disc_fixed = c->discFixed.data();
     c->device = device;
+    { const char* e = std::getenv("MCMC_HIP_COOP"); c->coop = e && std::atoi(e) != 0; }
     c->size = cfg->max_delay + cfg->n_predict + cfg->n_data;          /* covid.h:297 */
     c->nB = cfg->n_data - cfg->fix_behavior_in_advance;               /* covid.h:299 */
     c->dim = c->nB + cfg->n_disc + 3;

@@ -495,15 +495,49 @@ __device__ __forceinline__ void lag_tail(double (&acc)[A_NPOS][T], const double 
 /* rows of the history arrays are offset so that index k = -HOFF is row 0 */
 #define MCMC_HOFF(T) (2 * (T))
 
+/* ------------------------------------------------ cooperative pair of waves (COOP) ---- */
+/* Two waves of one workgroup work on ONE tile of 64 chains, so that every SIMD holds two
+ * waves (a lone wave issues an FP64 multiply-add only every ~5 cycles).  The 8-day blocks of a
+ * pass alternate between them: role r owns the blocks with (block index & 1) == r.  For its
+ * block b a wave first runs the lag chunks whose source days are final (chunks 0..b-2, they
+ * end before the partner's block b-1), then waits until the partner has published block b-1,
+ * and finishes with the last chunk, the tail and the sequential days.  Role 0 also does what
+ * is per chain and step: proposal, likelihood pass, accept.
+ * The pair talks through four LDS words: [0] blocks published (monotone over the launch),
+ * [1] proposals published (monotone), [2] keLo, [3] keHi (the day range with capacity
+ * corrections of the current pass).  History rows travel through global memory; the waves
+ * share the CU's vector L1, so a release/acquire pair at workgroup scope orders them. */
+#ifndef MCMC_COOP_SPIN_LIMIT
+#define MCMC_COOP_SPIN_LIMIT (1 << 22)
+#endif
+struct PairSync {
+    volatile int* w;
+    int role;
+    int* err;              /* global error word: set if a wait ran into the spin limit */
+};
+__device__ __forceinline__ void pair_signal(const PairSync& ps, int idx, int v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    ps.w[idx] = v;
+}
+__device__ __forceinline__ void pair_wait(const PairSync& ps, int idx, int v) {
+    int spins = 0;
+    while (__builtin_amdgcn_readfirstlane(ps.w[idx]) < v) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > MCMC_COOP_SPIN_LIMIT) { *ps.err = 1; break; }    /* never hang the GPU */
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 /*
  * DiseaseSpread::eval (covid.h:325-496) for the chain of this lane.  Returns loglike.
  * pairs += number of (day,lag) pairs the reference performs for this evaluation over the
  * full horizon `size` (the SURVEY 8d work unit).
  */
-template <int T, bool FUSE, bool DERIVE>
+template <int T, bool FUSE, bool DERIVE, bool COOP = false>
 __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& lds, const WaveBases& B,
                                              const LaneScalars& lp, unsigned lane, unsigned long long& pairs,
-                                             PhaseClock& pc) {
+                                             PhaseClock& pc, const PairSync* ps = nullptr, int* passCounter = nullptr) {
+    static_assert(!(COOP && DERIVE), "the derive kernel is single-wave");
     const int md = M.md;
     const int horizon = DERIVE ? M.size : M.simDays;
     const double* xdisc_u = B.x_u + M.nB * MCMC_WAVE;
@@ -529,13 +563,18 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
 
         /* zero the 2T history rows below ws (read as k < ws by the first blocks) and plant
          * patient zero (covid.h:339): n_s = 1, n_k = 0 for k < s */
-#pragma unroll 1
-        for (int k = ws - 2 * T; k < ws; ++k) {
-            B.hn_u[(k + MCMC_HOFF(T)) * MCMC_WAVE + lane] = 0.0;
-            B.he_u[(k + MCMC_HOFF(T)) * MCMC_WAVE + lane] = 0.0;
-        }
         double ncur = (s == ws) ? 1.0 : 0.0;
-        B.hn_u[(ws + MCMC_HOFF(T)) * MCMC_WAVE + lane] = ncur;
+        int fbase = 0;                        /* COOP: value of the block counter before this pass */
+        if constexpr (COOP) fbase = ((*passCounter)++) * 4096;
+        if (!COOP || ps->role == 0) {
+#pragma unroll 1
+            for (int k = ws - 2 * T; k < ws; ++k) {
+                B.hn_u[(k + MCMC_HOFF(T)) * MCMC_WAVE + lane] = 0.0;
+                B.he_u[(k + MCMC_HOFF(T)) * MCMC_WAVE + lane] = 0.0;
+            }
+            B.hn_u[(ws + MCMC_HOFF(T)) * MCMC_WAVE + lane] = ncur;
+            if constexpr (COOP) { ps->w[2] = 0x7fffffff; ps->w[3] = -1; }   /* published with block 0 */
+        }
 
         if constexpr (DERIVE) {
             /* days before the wave's first start: all buffers are zero there */
@@ -575,7 +614,10 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
             double beh[T];
             /* ------------- phase A: sources k < j0, lags descending = k ascending */
             const int b = (j0 - ws) / T;                     /* full chunks of T lags */
-            const bool anyE = keHi >= keLo;
+            if constexpr (COOP) { if ((b & 1) != ps->role) continue; }   /* the partner's block */
+            /* chunks [c0, bRun) run now; COOP keeps the last one for after the hand-over */
+            const int bRun = COOP ? max(b - 1, 0) : b;
+            bool anyE = keHi >= keLo;
             int Lc = j0 - ws + T - 1;                        /* first lag of chunk 0 */
             int c0 = 0;
             /* lags >= nLagRows are rows of zeros (the d < nDays cut-off of project(),
@@ -596,19 +638,20 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
              * [keLo, keHi]; chunk c reads source days [a0+c*T, a0+c*T+2T-2].  So the chunks
              * split into three runs: plain, with e-terms, plain.  Each run is a loop of its own
              * (two chunks per iteration, the window halves swapping roles). */
-            int cLo = b, cHi = b - 1;
+            const int c0r = min(c0, bRun);
+            int cLo = bRun, cHi = bRun - 1;
             if (anyE) {
                 const int num = keLo - a0 - 2 * T + 2;
                 cLo = num <= 0 ? 0 : (num + T - 1) / T;
                 cHi = (keHi - a0) / T;
-                cLo = max(cLo, c0);
-                cHi = min(cHi, b - 1);
-                if (cHi < cLo) { cLo = b; cHi = b - 1; }
+                cLo = max(cLo, c0r);
+                cHi = min(cHi, bRun - 1);
+                if (cHi < cLo) { cLo = bRun; cHi = bRun - 1; }
             }
             const double* ek0 = ebase + cLo * T * MCMC_WAVE;
 #pragma unroll 1
             for (int seg = 0; seg < 3; ++seg) {
-                int nch = (seg == 0) ? cLo - c0 : (seg == 1) ? cHi - cLo + 1 : b - 1 - cHi;
+                int nch = (seg == 0) ? cLo - c0r : (seg == 1) ? cHi - cLo + 1 : bRun - 1 - cHi;
                 pc.count(seg == 1 ? PH_NCHUNK_E : PH_NCHUNK, nch);
                 /* The lane index the lag loops address with is re-defined here, as an opaque
                  * copy.  Otherwise the compiler may reload its (spilled) 64-bit lane offset
@@ -689,11 +732,47 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                 pcfv[t] = sg >= 0 ? dv : 1.0;
             }
             pc.stamp(PH_CHUNKS);
-            /* the tail reads source days [j0-T+1, j0-1] */
-            if (anyE && j0 - T + 1 <= keHi && j0 - 1 >= keLo)
-                lag_tail<T, FUSE, true>(acc, WA, lds.Rpos, lds.Rneg, ebase + b * T * MCMC_WAVE, lane, RR);
-            else
-                lag_tail<T, FUSE, false>(acc, WA, lds.Rpos, lds.Rneg, nullptr, lane, RR);
+            if constexpr (COOP) {
+                /* hand-over: the partner has published block b-1 (days j0-T .. j0-1, n_{j0} and
+                 * its part of the correction range); now the last chunk and the tail can run */
+                if (b > 0) pair_wait(*ps, 0, fbase + b);
+                keLo = min(keLo, __builtin_amdgcn_readfirstlane(ps->w[2]));
+                keHi = max(keHi, __builtin_amdgcn_readfirstlane(ps->w[3]));
+                anyE = keHi >= keLo;
+                const double* lrow = B.hn_u + (j0 - 2 * T + 1 + MCMC_HOFF(T)) * MCMC_WAVE;
+                const double* erow = B.he_u + (j0 - 2 * T + 1 + MCMC_HOFF(T)) * MCMC_WAVE;
+                double LN[T];                 /* n of the days j0-T+1 .. j0 */
+#pragma unroll
+                for (int q = 0; q < T; ++q) LN[q] = lrow[(q + T) * MCMC_WAVE + lane];
+                if (b >= 1 && c0 <= b - 1) {                 /* chunk b-1: lags 2T-1 .. T */
+                    double LW[T];
+#pragma unroll
+                    for (int q = 0; q < T; ++q) LW[q] = lrow[q * MCMC_WAVE + lane];
+                    if (anyE && j0 - 2 * T + 1 <= keHi && j0 - 1 >= keLo) {
+                        double LEW[T], LEN[T];
+#pragma unroll
+                        for (int q = 0; q < T; ++q) {
+                            LEW[q] = erow[q * MCMC_WAVE + lane];
+                            LEN[q] = erow[(q + T) * MCMC_WAVE + lane];
+                        }
+                        double4_t rn = lds_row4(lds.Rneg, Lc);
+                        lag_chunk_e<T, FUSE>(acc, LW, LN, LEW, LEN, r, rn, lds.Rpos, lds.Rneg, Lc, lrow, erow, lane);
+                    } else {
+                        lag_chunk<T, FUSE>(acc, LW, LN, r, lds.Rpos, Lc, lrow, lane);
+                    }
+                }
+                if (anyE && j0 - T + 1 <= keHi && j0 - 1 >= keLo)
+                    lag_tail<T, FUSE, true>(acc, LN, lds.Rpos, lds.Rneg, ebase + b * T * MCMC_WAVE, lane, RR);
+                else
+                    lag_tail<T, FUSE, false>(acc, LN, lds.Rpos, lds.Rneg, nullptr, lane, RR);
+                ncur = LN[T - 1];
+            } else {
+                /* the tail reads source days [j0-T+1, j0-1] */
+                if (anyE && j0 - T + 1 <= keHi && j0 - 1 >= keLo)
+                    lag_tail<T, FUSE, true>(acc, WA, lds.Rpos, lds.Rneg, ebase + b * T * MCMC_WAVE, lane, RR);
+                else
+                    lag_tail<T, FUSE, false>(acc, WA, lds.Rpos, lds.Rneg, nullptr, lane, RR);
+            }
             pc.stamp(PH_TAIL);
             /* the window registers are free now: request the first window of the NEXT block
              * before the sequential phase B, unless this block is about to write into it
@@ -798,7 +877,18 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                     WB[q] = hbase[(q + T) * MCMC_WAVE + lane];
                 }
             }
+            if constexpr (COOP) {             /* publish the block: history rows, correction range */
+                ps->w[2] = keLo;
+                ps->w[3] = keHi;
+                pair_signal(*ps, 0, fbase + b + 1);
+            }
             pc.stamp(PH_DAYS);
+        }
+        if constexpr (COOP) {
+            /* the likelihood pass is role 0's, once every block of the pass is published */
+            if (ps->role != 0) continue;
+            const int nb = (horizon - ws + T - 1) / T;
+            if (nb > 0) pair_wait(*ps, 0, fbase + nb);
         }
 
         /* log-likelihood of this pass (covid.h:488-492), data days in order: the output
@@ -1139,6 +1229,142 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
     }
     pc.flush(lane);
 
+    rng_u[lane] = rnd.state;
+    ll_u[lane] = llModel;
+    ll_u[MCMC_WAVE + lane] = llPrior;
+    S.stepsize[flat] = stepsize;
+    S.nAccept[flat] = nAccept;
+    S.pairs[flat] = pairs;
+}
+
+/* The same MH steps with a cooperative pair of waves per tile (see "cooperative pair"):
+ * workgroups of 8 waves = 4 tiles, role = wave & 1.  Results are bit-identical to
+ * mh_step_kernel: the arithmetic of a chain and its order do not change, only which wave
+ * executes it. */
+#define MCMC_COOP_BLOCK (2 * MCMC_BLOCK)
+#define MCMC_COOP_SYNC_BYTES 128
+__host__ __device__ inline size_t coop_sync_offset(const DevModel& M, int T) {
+    return (lds_bytes(M, false, T) + 15) & ~(size_t)15;
+}
+template <int T, bool FUSE>
+__global__ __launch_bounds__(MCMC_COOP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void mh_step_coop_kernel(DevModel M, ChainState S, int n_steps, const double* __restrict__ betas,
+                         const int* __restrict__ flags, int slot0, int* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    int* syncWords = (int*)((char*)lds_raw + coop_sync_offset(M, T));
+    if (threadIdx.x < MCMC_COOP_SYNC_BYTES / 4) syncWords[threadIdx.x] = 0;
+    const LdsView lds = stage_lds(M, lds_raw, false, T);            /* ends with the workgroup barrier */
+    const unsigned lane = threadIdx.x & (MCMC_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / MCMC_WAVE));
+    /* waves w and w+4 of a workgroup share a SIMD: they are one pair, so that the SIMD has
+     * the eval work of both roles and role 0's per-step work alone */
+    const int pairIdx = wave & (MCMC_WAVES_PER_BLOCK - 1);
+    const int tile = (int)blockIdx.x * MCMC_WAVES_PER_BLOCK + pairIdx;
+    if (tile >= S.nTiles) return;
+    PairSync ps;
+    ps.w = (volatile int*)(syncWords + pairIdx * 8);
+    ps.role = wave / MCMC_WAVES_PER_BLOCK;
+    ps.err = err;
+    int passCounter = 0;
+    const size_t tileVec = (size_t)S.dim * MCMC_WAVE;
+    const double* xc_u = S.params + (size_t)tile * tileVec;
+    double* xcw_u = S.params + (size_t)tile * tileVec;
+    double* xp_u = S.prop + (size_t)tile * tileVec;
+    uint64_t* rng_u = S.rng + (size_t)tile * 2 * MCMC_WAVE;
+    double* ll_u = S.ll + (size_t)tile * 2 * MCMC_WAVE;
+    const size_t flat = (size_t)tile * MCMC_WAVE + lane;
+    const WaveBases B = wave_bases(M, S, tile, xp_u);
+    PhaseClock pc;
+    pc.start();
+    unsigned long long pairs = 0;
+
+    if (ps.role == 1) {                       /* the helper: its half of every model evaluation */
+#pragma unroll 1
+        for (int g = 0; g < n_steps; ++g) {
+            pair_wait(ps, 1, g + 1);                                /* proposal g is in xp_u */
+            LaneScalars lp;
+            load_lane_scalars(M, xp_u, lane, lp);
+            (void)eval_model<T, FUSE, false, true>(M, lds, B, lp, lane, pairs, pc, &ps, &passCounter);
+        }
+        return;
+    }
+
+    Pcg32 rnd;
+    rnd.state = rng_u[lane];
+    rnd.inc = rng_u[MCMC_WAVE + lane];
+    double llModel = ll_u[lane], llPrior = ll_u[MCMC_WAVE + lane];
+    double stepsize = S.stepsize[flat];
+    int nAccept = S.nAccept[flat];
+    pairs = S.pairs[flat];
+    int slot = slot0;
+    const double rungBeta = S.chainBeta ? S.chainBeta[flat] : 1.0;
+
+#pragma unroll 1
+    for (int g = 0; g < n_steps; ++g) {
+        const int fl = flags[g];
+        const double beta = betas[g] * rungBeta;
+        if (fl & SF_RESET_ACC) nAccept = 0;
+        if (fl & SF_RECORD) {
+            double l = 0;
+            l += llModel;
+            if (M.hasPrior) l += llPrior;
+            S.recLL[((size_t)slot * S.nTiles + tile) * MCMC_WAVE + lane] = 0.0 + beta * l;
+            if (S.recSamples) {
+                double* dst = S.recSamples + ((size_t)slot * S.nTiles + tile) * tileVec;
+                for (int k = 0; k < S.dim; ++k) dst[k * MCMC_WAVE + lane] = xc_u[k * MCMC_WAVE + lane];
+            }
+            ++slot;
+        }
+        if ((fl & SF_MEAN) && S.mean) {
+            double* mu = S.mean + (size_t)tile * tileVec;
+            for (int k = 0; k < S.dim; ++k) mu[k * MCMC_WAVE + lane] += xc_u[k * MCMC_WAVE + lane];
+        }
+        if (fl & SF_RANDOM) {
+            const int nState = M.hasPrior ? 2 : 1;
+            int head;
+            do {
+                const float f = rnd.next_float() * (float)nState;
+                head = min((int)f, nState - 1);
+            } while (head != 0);
+        }
+        LaneScalars lp;
+        double llpNew;
+        const bool behChanged = propose(M, rnd, xc_u, xp_u, lane, stepsize, lp, llpNew);
+        pair_signal(ps, 1, g + 1);
+        const double llm = eval_model<T, FUSE, false, true>(M, lds, B, lp, lane, pairs, pc, &ps, &passCounter);
+        double llp = 0.0;
+        double delta = 0;
+        delta += -llModel + llm;
+        if (M.hasPrior) {
+            llp = behChanged ? llpNew : llPrior;
+            delta += -llPrior + llp;
+        }
+        delta += 0.0;
+        delta *= beta;
+        const double u = (double)rnd.next_float();
+        const bool accept = u < 1.0 * mcmc_exp(delta);
+        if (__any(accept)) {
+            constexpr int AB = MCMC_ACC_BATCH;
+#pragma unroll 1
+            for (int k0 = 0; k0 < S.dim; k0 += AB) {
+                double vv[AB];
+#pragma unroll
+                for (int j = 0; j < AB; ++j) vv[j] = xp_u[min(k0 + j, S.dim - 1) * MCMC_WAVE + lane];
+#pragma unroll
+                for (int j = 0; j < AB; ++j)
+                    if (accept && k0 + j < S.dim) xcw_u[(k0 + j) * MCMC_WAVE + lane] = vv[j];
+            }
+        }
+        if (accept) {
+            llModel = llm;
+            llPrior = llp;
+            ++nAccept;
+        }
+        if (fl & SF_ADJUST_END) {
+            const double acceptRate = (double)nAccept / 20;
+            stepsize *= rate2corr(acceptRate);
+        }
+    }
     rng_u[lane] = rnd.state;
     ll_u[lane] = llModel;
     ll_u[MCMC_WAVE + lane] = llPrior;
