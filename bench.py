@@ -100,7 +100,9 @@ def ess_leg(cfg, R, device, contract, xs, stepsizes, first_id, n_steps, thinning
     s.close()
     names = ["betaMild", "betaHigh", "delay"]
     per_step = {nm: float(ess_geyer(tail[:, :, j]).sum() / (n * n_steps)) for j, nm in enumerate(names)}
-    return {"ess_per_step": per_step, "acceptance": float(acc),
+    from mcmc_amd.sharding import moment_sums, rhat_ess
+    rhat, _ = rhat_ess(moment_sums(tail), 3, n_saved)                # Gelman-Rubin over the recorded stretch
+    return {"ess_per_step": per_step, "acceptance": float(acc), "rhat": dict(zip(names, map(float, rhat))),
             "sample": f"{n} chains x {n_steps} steps after the adaptation, every {thinning}th point, Geyer initial "
                       "positive sequence per chain, summed over chains"}
 

@@ -9,21 +9,32 @@
  *
  * PINNING STATUS.  The reference cannot be compiled in this image (all five submodules
  * -- pcg32, enoki, tbb, pybind11, eigen -- are empty directories and covid.h is not part
- * of the reference's own build), and the reference has no tests, golden vectors or
- * recorded numeric outputs for this path.  What is pinned:
+ * of the reference's own build) and it has no tests or golden vectors.  What is pinned:
  *   - pcg32 seed/nextUInt: the published PCG32 known-answer vector pcg32(42,54)
- *     (tests/golden/pcg32_kat.json).
+ *     (tests/golden/pcg32_kat.json);
+ *   - the Metropolis-Hastings machinery, against OUTPUTS OF THE REFERENCE ITSELF: the
+ *     author saved notebooks/test2.ipynb with its outputs, and the chain samples printed
+ *     there (FourGaussians(6) under TempTarget(10) after 5.2 million steps; chain 0 of a
+ *     100 000-candidate reservoir ChainManager) are reproduced to every printed digit
+ *     (tests/golden/test2_ipynb_outputs.json + README, tests/test_oracle_cpu.py::
+ *     test_reference_notebook_outputs).  That pins pcg32(0, id) seeding, nextFloat and
+ *     nextDouble, the one float step_random_subspace consumes per step, bound(), the
+ *     accept rule u < exp(beta*delta), TempTarget's beta, the 20-step adjust groups with
+ *     rate2corr, burn-in / thinning, sampleInitialConditions, the bootstrap and chain
+ *     ids i+1.
  * What is NOT pinned by any reference artefact ("parity unpinned"):
- *   - pcg32::nextFloat/nextDouble bit tricks (restated from the published
- *     wjakob/pcg32 header: (u>>9)|0x3f800000 and (u64(u)<<20)|0x3ff0..., minus 1);
- *   - enoki::erfinv (restated as M. Giles' published single-precision polynomial);
- *     only used for the one-off response-table precompute, which is an explicit INPUT
- *     to both this oracle and the HIP path, so it cannot cause a mismatch;
- *   - every floating-point result: this restatement follows the C++ source expression
- *     by expression with contraction off (the author's 2020 clang default), see the
- *     `contract` flag for the gcc -ffp-contract=fast variant of the projection loop.
- *   - std::cos / std::exp: replaced by include/mcmc_detmath.h (<= 1 ulp from glibc);
- *     `use_libm` switches the oracle back to libm to measure the effect.
+ *   - the covid model (DiseaseSpread::step / eval, SmoothnessPrior): the only recorded
+ *     outputs (notebooks/covid*.ipynb) come from an older revision of covid.h with a
+ *     different interface and capacity formula.  Restated expression by expression, with
+ *     contraction off (the author's 2020 clang default); see the `contract` flag for the
+ *     -ffp-contract=fast variant of the projection loop;
+ *   - enoki::erfinv (restated as M. Giles' published single-precision polynomial); only
+ *     used for the one-off response-table precompute, which is an explicit INPUT to both
+ *     this oracle and the HIP path, so it cannot cause a mismatch;
+ *   - std::cos / std::exp / std::log: replaced by include/mcmc_detmath.h (<= 1 ulp from
+ *     glibc); `use_libm` switches the oracle back to libm to measure the effect.  (The
+ *     notebook pin above passes with them, i.e. no accept decision in 5.2 million steps
+ *     falls inside that last ulp.)
  */
 #ifndef MCMC_ORACLE_H
 #define MCMC_ORACLE_H

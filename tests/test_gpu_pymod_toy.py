@@ -138,3 +138,19 @@ def test_plain_manager_and_generator_manager():
     assert np.array_equal(cm2.saved_sample(0), pts[picks])
     ll, smp, _, _ = O.fourgauss_run(6.0, 1.0, 5, pts[picks[4]], 100, 0, 0, 10, stepsize=ss * (1 / 5.))
     assert np.array_equal(cm2.get_chain(4).get_loglikes(), ll)
+
+
+def test_module_reproduces_the_reference_notebook_reservoir_flow(capfd):
+    """notebooks/test2.ipynb cell 8 as saved by the reference's author (tests/golden/
+    test2_ipynb_outputs.json + README): ChainManager(TempTarget(1), 100000, 1000) -- a reservoir
+    of sampleInitialConditions draws, bootstrap -- then 100 steps; the printed samples of chain 0
+    are its states one step after every 10th iteration."""
+    import json
+    from conftest import GOLDEN
+    g = json.load(open(os.path.join(GOLDEN, "test2_ipynb_outputs.json")))
+    lh, s, t2 = _four_gaussians(1.0)
+    cm = mcmc.ChainManager(t2, 100000, 1000)
+    cm.run_all_adjust(100, 1, 1.0, 1)                  # = run_all(nSteps, thinning, stepsizefac, nThread)
+    capfd.readouterr()                                 # the reference's progress prints
+    got = np.array([cm.saved_sample(10 * k + 1)[0] for k in range(1, 10)])
+    assert np.allclose(got, g["cell8"]["chain0_pos"], rtol=0, atol=5.1e-9)

@@ -56,3 +56,23 @@ def test_toy_eval_and_errors():
     with pytest.raises(H.McmcHipError):
         H.toy_run("mylike1", np.ones((2, 3)), 10, 0, 0, 0)       # thinning 0
     assert H.lib().mcmc_hip_toy_dim(7) < 0
+
+
+def test_gpu_chain_reproduces_the_reference_notebook():
+    """notebooks/test2.ipynb as saved by the reference's author (tests/golden/
+    test2_ipynb_outputs.json + README): the GPU chain, 5.2 million steps on, prints the same
+    samples.  Printed sample k of cell 5 is the state one step after saved point 101 + k."""
+    import json, os
+    from conftest import GOLDEN
+    g = json.load(open(os.path.join(GOLDEN, "test2_ipynb_outputs.json")))
+    tol = 5.1e-9
+    burn = 505000
+    r = H.toy_run("fourgauss", [[0.0, 0.0]], 5000000, burn, 10000, 1, difficulty=6.0, target="temp", T=10.0,
+                  first_chain_id=0)
+    st = r["samples"][0]                                # st[k] = state at iteration burn + k
+    first = 500000 + 50 * 101 + 1 - burn
+    last = 500000 + 50 * (90200 - 1) + 1 - burn
+    head, tail = st[[first, first + 50, first + 100]], st[[last - 100, last - 50, last]]
+    c5 = g["cell5"]
+    assert np.allclose(head[:, 0], c5["x_head"], rtol=0, atol=tol) and np.allclose(head[:, 1], c5["y_head"], rtol=0, atol=tol)
+    assert np.allclose(tail[:, 0], c5["x_tail"], rtol=0, atol=tol) and np.allclose(tail[:, 1], c5["y_tail"], rtol=0, atol=tol)

@@ -292,3 +292,40 @@ def test_toy_mylike1_cli_config_statistics():
 def test_toy_four_gaussians_tempered():
     ll, s, sf, nacc = O.fourgauss_run(6.0, 10.0, 0, np.zeros(2), 20000, 0, 200, 10)
     assert np.all(np.isfinite(ll)) and np.all(np.abs(s) <= 5.0) and nacc > 0
+
+
+def test_reference_notebook_outputs():
+    """The outputs the reference's author recorded in notebooks/test2.ipynb (tests/golden/
+    test2_ipynb_outputs.json, README_test2_ipynb.md): 5.2 million MH steps of FourGaussians(6)
+    under TempTarget(10), and chain 0 of a 100 000-candidate reservoir ChainManager."""
+    import json
+    g = json.load(open(os.path.join(GOLDEN, "test2_ipynb_outputs.json")))
+    tol = 5.1e-9                                           # printed with 8 decimals
+    # cell 5: printed sample k = state one step after saved point 101 + k (see the README)
+    _, st, _, _ = O.fourgauss_run(6.0, 10.0, 0, [0.0, 0.0], 5000000, 0, 10000, 1)   # every iteration
+    first = 500000 + 50 * 101 + 1
+    last = 500000 + 50 * (90200 - 1) + 1
+    head = st[[first, first + 50, first + 100]]
+    tail = st[[last - 100, last - 50, last]]
+    c5 = g["cell5"]
+    assert np.allclose(head[:, 0], c5["x_head"], rtol=0, atol=tol) and np.allclose(head[:, 1], c5["y_head"], rtol=0, atol=tol)
+    assert np.allclose(tail[:, 0], c5["x_tail"], rtol=0, atol=tol) and np.allclose(tail[:, 1], c5["y_tail"], rtol=0, atol=tol)
+    # cell 8: reservoir of 100 000 sampleInitialConditions draws from pcg32(0,0) (test.h:116-123,
+    # mcmc.h:1348-1374), bootstrap (mcmc.h:1599-1650), chain 0 has id 1 (mcmc.h:1487)
+    L = O.lib()
+    r = O.Rng(0, 0)
+    cand, lls = [], []
+    while len(cand) < 100000:
+        x = np.array([-5 + 10 * r.next_double(), -5 + 10 * r.next_double()])
+        l = L.orc_fourgauss_eval(6.0, x.ctypes.data_as(O.C.POINTER(O.C.c_double)))
+        if np.isfinite(l):
+            cand.append(x)
+            lls.append(l)
+    lls = np.array(lls)
+    w = np.exp(lls - lls.max())
+    cdf = np.cumsum(w)
+    total = w.sum()
+    cdf[-1] = 1.000001 * total
+    pick0 = int(np.searchsorted(cdf, r.next_double() * total, side="right"))
+    _, st, _, _ = O.fourgauss_run(6.0, 1.0, 1, cand[pick0], 100, 0, 0, 1)
+    assert np.allclose(st[[10 * k + 1 for k in range(1, 10)]], g["cell8"]["chain0_pos"], rtol=0, atol=tol)
