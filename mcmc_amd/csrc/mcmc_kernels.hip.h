@@ -928,17 +928,31 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
     return loglike;
 }
 
+/* t / dx / dx / dx of SmoothnessPrior::eval (mcmc.h:208).  When dx = L/n is a power of two
+ * (the notebooks' L = n gives dx = 1) each division is the multiplication by the exact
+ * reciprocal: the same real number rounded once, hence the same double -- without the three
+ * ~12-instruction division sequences per element.  The branch is wave-uniform. */
+__device__ __forceinline__ bool is_pow2(double x) {
+    return x > 0 && (__double_as_longlong(x) & 0x000fffffffffffffLL) == 0 && x < 1e300 && x > 1e-300;
+}
+__device__ __forceinline__ double div3(double t, double dx, bool pow2, double inv) {
+    if (pow2) return t * inv * inv * inv;
+    return t / dx / dx / dx;
+}
+
 /* SmoothnessPrior::eval (mcmc.h:197-214) on behavior = x[0..nB) */
 __device__ inline double eval_prior(const DevModel& M, const double* x_u, unsigned lane) {
     const int n = M.nB;
     const double dx = M.smoothL / (double)n;
+    const bool dxPow2 = is_pow2(dx);
+    const double invDx = 1.0 / dx;
     double loglike = 0;
     double fm = x_u[lane], f0 = x_u[MCMC_WAVE + lane];
 #pragma unroll 4
     for (int i = 1; i + 1 < n; ++i) {
         const double fp = x_u[(i + 1) * MCMC_WAVE + lane];
         const double dd = fp + fm - 2 * f0;
-        loglike -= dd * dd / dx / dx / dx;
+        loglike -= div3(dd * dd, dx, dxPow2, invDx);
         fm = f0;
         f0 = fp;
     }
@@ -1030,6 +1044,8 @@ __device__ inline bool propose(const DevModel& M, Pcg32& rnd, const double* __re
     if (__any(doB)) {
         const int n = M.nB;
         const double dx = M.smoothL / (double)n;
+        const bool dxPow2 = is_pow2(dx);
+        const double invDx = 1.0 / dx;
         double loglike = 0;
         double fm = 0, f0 = 0;
         constexpr int PB = MCMC_PROP_BATCH;   /* loads of a trip are requested together */
@@ -1050,7 +1066,7 @@ __device__ inline bool propose(const DevModel& M, Pcg32& rnd, const double* __re
                     xp_u[i * MCMC_WAVE + lane] = v;
                     if (i >= 2) {
                         const double dd = v + fm - 2 * f0;
-                        loglike -= dd * dd / dx / dx / dx;
+                        loglike -= div3(dd * dd, dx, dxPow2, invDx);
                     }
                     fm = f0;
                     f0 = v;

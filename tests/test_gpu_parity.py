@@ -126,6 +126,27 @@ def test_long_horizon_beyond_the_trajectory_table(R11, R10):
     s.close()
 
 
+@pytest.mark.parametrize("scale", [1.0, 0.25, 8.0, 1.0 / 3.0, 37.3])
+def test_smoothness_prior_scales(R11, R10, scale):
+    """dx = L/n of SmoothnessPrior (mcmc.h:201): the kernels multiply by the exact reciprocal when
+    dx is a power of two (1, 1/4, 8) and divide otherwise (1/3, 37.3/n) -- same bits either way."""
+    base = make_cfg(40, R11, **SMALL)
+    L = 37.3 if scale == 37.3 else base["nB"] * scale
+    cfg = make_cfg(40, R11, smooth_L=L, smooth_Ls=17.0, **SMALL)
+    m = O.Model(cfg, R11)
+    xs = perturbed(cfg, 64, 0.1)
+    s = H.CovidSampler(cfg, R10)
+    ll = s.eval(xs)
+    assert np.array_equal(ll[:, 1], np.array([m.prior(x) for x in xs]))
+    tgt = O.make_target("temp", 1.0)
+    s.set_chains(xs)
+    s.step(12, 1.0, True)
+    st = _state(s)
+    for c in (0, 31, 63):
+        _assert_chain_equal(_oracle_after_steps(m, tgt, c + 1, xs[c], 12), st, c)
+    s.close()
+
+
 def test_eval_nonfinite_parameters_do_not_fault(R11, R10):
     """NaN/Inf parameters (the reference rejects such initial states, mcmc.h:1334,1365): the
     kernel must stay in bounds and report a non-finite or oracle-equal loglike."""
