@@ -1,0 +1,27 @@
+"""Build-time guard on the generated code of the step kernel's two lag loops (no GPU needed:
+hipcc cross-compiles gfx950).  What it protects is measured in DESIGN.md section 5: a full
+vmcnt(0) wait or scratch traffic inside these loops costs 5-10 % of the whole benchmark and
+comes and goes with unrelated source changes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_lag_loops_keep_their_prefetch_in_flight(tmp_path):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_guard.py"), str(tmp_path)],
+                         check=True, capture_output=True, text=True, timeout=600).stdout
+    r = json.loads(out.strip().splitlines()[-1])
+    plain, eterm = r["plain_loop"], r["eterm_loop"]
+    # two chunks of 8 lag steps per iteration: 56 (88) multiply-adds per step plus <= 10 others
+    assert plain["fp64_ops"] == 896 and plain["instructions"] <= 1060
+    assert eterm["fp64_ops"] == 1408 and eterm["instructions"] <= 1700
+    assert plain["scratch"] == 0 and eterm["scratch"] == 0
+    # the history window is refilled two chunks ahead: waits inside the loops must leave at
+    # least one chunk's worth of loads (8, resp. 16 with the e-window) outstanding
+    assert plain["min_vmcnt"] >= 8 and eterm["min_vmcnt"] >= 16

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Compiles the step kernel with -save-temps and reports on its two lag loops (the plain one:
+896 FP64 multiply-adds per iteration, the e-term one: 1408): instruction count, scratch
+accesses, and the tightest vmcnt wait inside the loop.  A vmcnt(0) there means the window
+prefetch is drained every iteration.  Used by tests/test_isa_cpu.py.
+usage: isa_guard.py [workdir]  -> prints one JSON object"""
+import collections, json, os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def analyse(workdir):
+    src = os.path.join(ROOT, "mcmc_amd", "csrc", "mcmc_hip.hip")
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "mcmc_amd", "csrc"), "-DMCMC_T=8",
+           "-Wno-unused-function", "-save-temps", "-c", src, "-o", os.path.join(workdir, "x.o")]
+    subprocess.run(cmd, cwd=workdir, check=True, capture_output=True)
+    asm = open(os.path.join(workdir, "mcmc_hip-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    m = re.search(r"^_Z14mh_step_kernelILi8ELb1EE[^\n]*:.*?\.end_amdhsa_kernel", asm, re.S | re.M)
+    body = m.group(0).split("\n")
+    blocks, cur = [], None
+    for line in body:
+        if re.match(r"^\.LBB\d+_\d+:", line):
+            cur = []
+            blocks.append(cur)
+        elif cur is not None:
+            t = line.strip()
+            if t and not t.startswith((";", ".")):
+                cur.append(t)
+    out = {}
+    for ins in blocks:
+        fma = sum(1 for t in ins if t.startswith(("v_fmac_f64", "v_fma_f64", "v_add_f64")))
+        name = {896: "plain_loop", 1408: "eterm_loop"}.get(fma)
+        if name is None or len(ins) < 900:
+            continue
+        waits = [int(x) for t in ins for x in re.findall(r"vmcnt\((\d+)\)", t)]
+        out[name] = {"instructions": len(ins), "fp64_ops": fma, "scratch": sum("scratch" in t for t in ins),
+                     "min_vmcnt": min(waits) if waits else None}
+    vg = re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(0))
+    out["vgprs"] = int(vg.group(1)) if vg else None
+    return out
+
+
+if __name__ == "__main__":
+    wd = sys.argv[1] if len(sys.argv) > 1 else tempfile.mkdtemp(prefix="isa_guard_")
+    os.makedirs(wd, exist_ok=True)
+    print(json.dumps(analyse(wd)))
