@@ -713,9 +713,9 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                 }
                 pc.stamp(seg == 1 ? PH_CHUNKS_E : PH_CHUNKS);
             }
-            /* what phase B needs from memory, requested before the tail's 7*T*(T-1)/2
-             * multiply-adds: the behaviour values of the block's days */
-            /* rows 0..T-1 across the lanes, for the tail and phase B of this block (re-read per
+            /* what phase B needs from memory is requested before the tail's 7*T*(T-1)/2
+             * multiply-adds: behaviour values and piecewise factors of the block's days.
+             * Rows 0..T-1 across the lanes, for the tail and phase B of this block (re-read per
              * block: six LDS reads, and the registers stay free during the lag loops) */
             RowRegs RR;
             if constexpr (FUSE && T == 8 && MCMC_DPP_ROWS) RR = load_row_regs(lds, lane);
@@ -789,8 +789,9 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const int i = j0 + t;
-                /* today's new infections into today and the rest of the block (covid.h:403-410).
-                 * The rows 0..T-1 are re-read from LDS every day (the opaque zero keeps the
+                /* today's new infections into today and the rest of the block (covid.h:403-410):
+                 * with FMA contraction from the rows held across the lanes (RowRegs); otherwise
+                 * the rows 0..T-1 are re-read from LDS every day (the opaque zero keeps the
                  * compiler from parking all of them in AccVGPRs, which costs two register
                  * moves per multiply-add) */
                 if constexpr (FUSE && T == 8 && MCMC_DPP_ROWS) {
