@@ -119,7 +119,7 @@ __device__ __forceinline__ double madd(double a, double b, double c) {
 /* Built with -DMCMC_STAMPS the kernels accumulate, per phase of an MH step, the shader
  * cycles (s_memtime) every wave spends there into g_phase_cycles; mcmc_hip_debug_phase_cycles
  * reads them.  Without the macro the hooks compile to nothing. */
-enum { PH_PROPOSE = 0, PH_SETUP, PH_CHUNKS, PH_TAIL, PH_DAYS, PH_LOGLIKE, PH_PRIOR, PH_ACCEPT, PH_RECORD, PH_CHUNKS_E, PH_NCHUNK, PH_NCHUNK_E, PH_COUNT };
+enum { PH_PROPOSE = 0, PH_SETUP, PH_CHUNKS, PH_TAIL, PH_DAYS, PH_LOGLIKE, PH_PRIOR, PH_ACCEPT, PH_RECORD, PH_CHUNKS_E, PH_NCHUNK, PH_NCHUNK_E, PH_WAIT, PH_COUNT };
 __device__ unsigned long long g_phase_cycles[16];
 #ifdef MCMC_STAMPS
 struct PhaseClock {
@@ -736,6 +736,7 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                 /* hand-over: the partner has published block b-1 (days j0-T .. j0-1, n_{j0} and
                  * its part of the correction range); now the last chunk and the tail can run */
                 if (b > 0) pair_wait(*ps, 0, fbase + b);
+                pc.stamp(PH_WAIT);
                 keLo = min(keLo, __builtin_amdgcn_readfirstlane(ps->w[2]));
                 keHi = max(keHi, __builtin_amdgcn_readfirstlane(ps->w[3]));
                 anyE = keHi >= keLo;
@@ -890,6 +891,7 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
             if (ps->role != 0) continue;
             const int nb = (horizon - ws + T - 1) / T;
             if (nb > 0) pair_wait(*ps, 0, fbase + nb);
+            pc.stamp(PH_WAIT);
         }
 
         /* log-likelihood of this pass (covid.h:488-492), data days in order: the output
@@ -1299,10 +1301,12 @@ void mh_step_coop_kernel(DevModel M, ChainState S, int n_steps, const double* __
 #pragma unroll 1
         for (int g = 0; g < n_steps; ++g) {
             pair_wait(ps, 1, g + 1);                                /* proposal g is in xp_u */
+            pc.stamp(PH_WAIT);
             LaneScalars lp;
             load_lane_scalars(M, xp_u, lane, lp);
             (void)eval_model<T, FUSE, false, true>(M, lds, B, lp, lane, pairs, pc, &ps, &passCounter);
         }
+        pc.flush(lane);
         return;
     }
 
@@ -1344,10 +1348,12 @@ void mh_step_coop_kernel(DevModel M, ChainState S, int n_steps, const double* __
                 head = min((int)f, nState - 1);
             } while (head != 0);
         }
+        pc.stamp(PH_RECORD);
         LaneScalars lp;
         double llpNew;
         const bool behChanged = propose(M, rnd, xc_u, xp_u, lane, stepsize, lp, llpNew);
         pair_signal(ps, 1, g + 1);
+        pc.stamp(PH_PROPOSE);
         const double llm = eval_model<T, FUSE, false, true>(M, lds, B, lp, lane, pairs, pc, &ps, &passCounter);
         double llp = 0.0;
         double delta = 0;
@@ -1381,7 +1387,9 @@ void mh_step_coop_kernel(DevModel M, ChainState S, int n_steps, const double* __
             const double acceptRate = (double)nAccept / 20;
             stepsize *= rate2corr(acceptRate);
         }
+        pc.stamp(PH_ACCEPT);
     }
+    pc.flush(lane);
     rng_u[lane] = rnd.state;
     ll_u[lane] = llModel;
     ll_u[MCMC_WAVE + lane] = llPrior;

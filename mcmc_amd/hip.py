@@ -321,7 +321,7 @@ class CovidSampler:
         _check(lib().mcmc_hip_last_timing(self._h, C.byref(a), C.byref(s), C.byref(k), C.byref(n)))
         return dict(adjust_s=a.value, sampling_s=s.value, step_kernel_s=k.value, launches=n.value)
 
-    PHASES = ["propose", "setup", "chunks", "tail", "days", "loglike", "prior", "accept", "record", "chunks_e", "n_chunks", "n_chunks_e"]
+    PHASES = ["propose", "setup", "chunks", "tail", "days", "loglike", "prior", "accept", "record", "chunks_e", "n_chunks", "n_chunks_e", "wait"]
 
     def phase_cycles(self, reset=False):
         out = np.zeros(16)
