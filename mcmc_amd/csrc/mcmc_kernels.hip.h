@@ -250,6 +250,25 @@ struct LaneScalars {
 __device__ __forceinline__ double8_t lds_row8(const double* Rpos, int L) {
     return *(const double8_t*)(Rpos + (size_t)L * 8);
 }
+#ifndef MCMC_SMEM_TABLE
+#define MCMC_SMEM_TABLE 1
+#endif
+/* The lag loops take their table rows through the SCALAR cache: one s_load_dwordx16 per lag
+ * step from the global copy of the table (rows are wave-uniform), and the 56 multiply-adds of
+ * the step read the row straight from SGPRs.  Against four LDS broadcast reads into 16 VGPRs
+ * per step this saves ~5 % of the loop's instructions and 32 VGPRs, measured +4 % on the
+ * whole benchmark.  (Reads only; nothing is ever written through the scalar cache.)
+ * MCMC_SMEM_TABLE=0 keeps the LDS rows.  Rows 0..T-1 of the sequential part, the e-term rows
+ * and the strict / derive paths use the LDS image. */
+#if MCMC_SMEM_TABLE
+#define MCMC_TAB(lds, M) (M).Rpos
+#else
+#define MCMC_TAB(lds, M) (lds).Rpos
+#endif
+typedef const __attribute__((address_space(4))) double8_t* const_row_ptr;
+__device__ __forceinline__ double8_t smem_row8(const double* RposGlobal, int L) {
+    return *(const_row_ptr)(RposGlobal + (size_t)L * 8);
+}
 __device__ __forceinline__ double4_t lds_row4(const double* Rneg, int L) {
     return *(const double4_t*)(Rneg + (size_t)L * 4);
 }
@@ -267,14 +286,22 @@ __device__ __forceinline__ double ld_row(const double* base_u, int row, unsigned
  * n[kbase + q].  After step u the slot W[u] is dead and is refilled with the history value
  * 2T further on (it becomes the `N` of the chunk after next: ping-pong, no register moves).
  * `r` carries the table row of the chunk's first lag in and that of the next chunk out, so
- * the LDS read of a row is always issued one full step (56 multiply-adds) ahead of use. */
+ * the read of a row (scalar load, or LDS with MCMC_SMEM_TABLE=0) is always issued one full
+ * step (56 multiply-adds) ahead of use. */
 template <int T, bool FUSE>
 __device__ __forceinline__ void lag_chunk(double (&acc)[A_NPOS][T], double (&W)[T], const double (&N)[T],
                                           double8_t& r, const double* Rpos, int Lc,
                                           const double* hn_next_u, unsigned lane) {
+#if MCMC_SMEM_TABLE
+    const double* rowBase = Rpos + (long long)(Lc - T) * 8;      /* rows Lc-T .. Lc-1, one address per chunk */
+#endif
 #pragma unroll
     for (int u = 0; u < T; ++u) {
+#if MCMC_SMEM_TABLE
+        const double8_t rnext = smem_row8(rowBase, T - 1 - u);
+#else
         const double8_t rnext = lds_row8(Rpos, Lc - u - 1);
+#endif
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int q = t + u;
@@ -290,6 +317,9 @@ __device__ __forceinline__ void lag_chunk(double (&acc)[A_NPOS][T], double (&W)[
         /* slot u of W is dead from here on: prefetch for the chunk after next */
         W[u] = ld_row(hn_next_u, u, lane);
         r = rnext;
+#if MCMC_SMEM_TABLE
+        __builtin_amdgcn_sched_barrier(0);      /* keep every step's prefetch in its step */
+#endif
     }
 }
 
@@ -303,9 +333,16 @@ __device__ __forceinline__ void lag_chunk_e(double (&acc)[A_NPOS][T], double (&W
                                             double (&EW)[T], const double (&EN)[T], double8_t& r, double4_t& rn,
                                             const double* Rpos, const double* Rneg, int Lc,
                                             const double* hn_next_u, const double* he_next_u, unsigned lane) {
+#if MCMC_SMEM_TABLE
+    const double* rowBase = Rpos + (long long)(Lc - T) * 8;
+#endif
 #pragma unroll
     for (int u = 0; u < T; ++u) {
+#if MCMC_SMEM_TABLE
+        const double8_t rnext = smem_row8(rowBase, T - 1 - u);
+#else
         const double8_t rnext = lds_row8(Rpos, Lc - u - 1);
+#endif
         const double4_t rnnext = lds_row4(Rneg, Lc - u - 1);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -632,7 +669,11 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                     WB[q] = hbase[(c0 * T + q + T) * MCMC_WAVE + lane];
                 }
             }
+#if MCMC_SMEM_TABLE
+            double8_t r = smem_row8(M.Rpos, Lc);
+#else
             double8_t r = lds_row8(lds.Rpos, Lc);
+#endif
             const double* hnx = hbase + (c0 + 2) * T * MCMC_WAVE;   /* refill source of chunk c0 */
             /* Source days that carry a capacity correction form the wave-uniform range
              * [keLo, keHi]; chunk c reads source days [a0+c*T, a0+c*T+2T-2].  So the chunks
@@ -665,13 +706,13 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                 if (seg != 1) {
 #pragma unroll 1
                     for (; nch >= 2; nch -= 2) {
-                        lag_chunk<T, FUSE>(acc, WA, WB, r, lds.Rpos, Lc, hnx, laneL);
-                        lag_chunk<T, FUSE>(acc, WB, WA, r, lds.Rpos, Lc - T, hnx + T * MCMC_WAVE, laneL);
+                        lag_chunk<T, FUSE>(acc, WA, WB, r, MCMC_TAB(lds, M), Lc, hnx, laneL);
+                        lag_chunk<T, FUSE>(acc, WB, WA, r, MCMC_TAB(lds, M), Lc - T, hnx + T * MCMC_WAVE, laneL);
                         hnx += 2 * T * MCMC_WAVE;
                         Lc -= 2 * T;
                     }
                     if (nch > 0) {
-                        lag_chunk<T, FUSE>(acc, WA, WB, r, lds.Rpos, Lc, hnx, laneL);
+                        lag_chunk<T, FUSE>(acc, WA, WB, r, MCMC_TAB(lds, M), Lc, hnx, laneL);
 #pragma unroll
                         for (int q = 0; q < T; ++q) { const double tmp = WA[q]; WA[q] = WB[q]; WB[q] = tmp; }
                         hnx += T * MCMC_WAVE;
@@ -696,15 +737,15 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
 #endif
 #pragma unroll 1
                     for (; nch >= 2; nch -= 2) {
-                        lag_chunk_e<T, FUSE>(acc, WA, WB, EA, EB, r, rn, lds.Rpos, lds.Rneg, Lc, hnx, ekx, laneL);
-                        lag_chunk_e<T, FUSE>(acc, WB, WA, EB, EA, r, rn, lds.Rpos, lds.Rneg, Lc - T,
+                        lag_chunk_e<T, FUSE>(acc, WA, WB, EA, EB, r, rn, MCMC_TAB(lds, M), lds.Rneg, Lc, hnx, ekx, laneL);
+                        lag_chunk_e<T, FUSE>(acc, WB, WA, EB, EA, r, rn, MCMC_TAB(lds, M), lds.Rneg, Lc - T,
                                              hnx + T * MCMC_WAVE, ekx + T * MCMC_WAVE, laneL);
                         hnx += 2 * T * MCMC_WAVE;
                         ekx += 2 * T * MCMC_WAVE;
                         Lc -= 2 * T;
                     }
                     if (nch > 0) {
-                        lag_chunk_e<T, FUSE>(acc, WA, WB, EA, EB, r, rn, lds.Rpos, lds.Rneg, Lc, hnx, ekx, laneL);
+                        lag_chunk_e<T, FUSE>(acc, WA, WB, EA, EB, r, rn, MCMC_TAB(lds, M), lds.Rneg, Lc, hnx, ekx, laneL);
 #pragma unroll
                         for (int q = 0; q < T; ++q) { const double tmp = WA[q]; WA[q] = WB[q]; WB[q] = tmp; }
                         hnx += T * MCMC_WAVE;
@@ -757,9 +798,9 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                             LEN[q] = erow[(q + T) * MCMC_WAVE + lane];
                         }
                         double4_t rn = lds_row4(lds.Rneg, Lc);
-                        lag_chunk_e<T, FUSE>(acc, LW, LN, LEW, LEN, r, rn, lds.Rpos, lds.Rneg, Lc, lrow, erow, lane);
+                        lag_chunk_e<T, FUSE>(acc, LW, LN, LEW, LEN, r, rn, MCMC_TAB(lds, M), lds.Rneg, Lc, lrow, erow, lane);
                     } else {
-                        lag_chunk<T, FUSE>(acc, LW, LN, r, lds.Rpos, Lc, lrow, lane);
+                        lag_chunk<T, FUSE>(acc, LW, LN, r, MCMC_TAB(lds, M), Lc, lrow, lane);
                     }
                 }
                 if (anyE && j0 - T + 1 <= keHi && j0 - 1 >= keLo)

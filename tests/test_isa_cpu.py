@@ -18,9 +18,9 @@ def test_lag_loops_keep_their_prefetch_in_flight(tmp_path):
                          check=True, capture_output=True, text=True, timeout=600).stdout
     r = json.loads(out.strip().splitlines()[-1])
     plain, eterm = r["plain_loop"], r["eterm_loop"]
-    # two chunks of 8 lag steps per iteration: 56 (88) multiply-adds per step plus <= 10 others
-    assert plain["fp64_ops"] == 896 and plain["instructions"] <= 1060
-    assert eterm["fp64_ops"] == 1408 and eterm["instructions"] <= 1700
+    # two chunks of 8 lag steps per iteration: 56 (88) multiply-adds per step plus <= 7 (12) others
+    assert plain["fp64_ops"] == 896 and plain["instructions"] <= 1010
+    assert eterm["fp64_ops"] == 1408 and eterm["instructions"] <= 1600
     assert plain["scratch"] == 0 and eterm["scratch"] == 0
     # the history window is refilled two chunks ahead: waits inside the loops must leave at
     # least one chunk's worth of loads (8, resp. 16 with the e-window) outstanding
