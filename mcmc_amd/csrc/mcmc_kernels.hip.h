@@ -253,6 +253,12 @@ __device__ __forceinline__ double8_t lds_row8(const double* Rpos, int L) {
 #ifndef MCMC_SMEM_TABLE
 #define MCMC_SMEM_TABLE 1
 #endif
+#ifndef MCMC_SMEM_LEAD2
+#define MCMC_SMEM_LEAD2 1      /* the row of lag step u+2 is requested during step u (+2 % over one step of lead) */
+#endif
+#ifndef MCMC_SMEM_LEAD2_E
+#define MCMC_SMEM_LEAD2_E 0
+#endif
 /* The lag loops take their table rows through the SCALAR cache: one s_load_dwordx16 per lag
  * step from the global copy of the table (rows are wave-uniform), and the 56 multiply-adds of
  * the step read the row straight from SGPRs.  Against four LDS broadcast reads into 16 VGPRs
@@ -294,10 +300,16 @@ __device__ __forceinline__ void lag_chunk(double (&acc)[A_NPOS][T], double (&W)[
                                           const double* hn_next_u, unsigned lane) {
 #if MCMC_SMEM_TABLE
     const double* rowBase = Rpos + (long long)(Lc - T) * 8;      /* rows Lc-T .. Lc-1, one address per chunk */
+#if MCMC_SMEM_LEAD2
+    double8_t r1 = smem_row8(rowBase, T - 1);
+#endif
 #endif
 #pragma unroll
     for (int u = 0; u < T; ++u) {
-#if MCMC_SMEM_TABLE
+#if MCMC_SMEM_TABLE && MCMC_SMEM_LEAD2
+        const double8_t rnext = r1;
+        r1 = smem_row8(rowBase, T - 2 - u);                          /* row Lc-u-2: two steps ahead */
+#elif MCMC_SMEM_TABLE
         const double8_t rnext = smem_row8(rowBase, T - 1 - u);
 #else
         const double8_t rnext = lds_row8(Rpos, Lc - u - 1);
@@ -335,10 +347,16 @@ __device__ __forceinline__ void lag_chunk_e(double (&acc)[A_NPOS][T], double (&W
                                             const double* hn_next_u, const double* he_next_u, unsigned lane) {
 #if MCMC_SMEM_TABLE
     const double* rowBase = Rpos + (long long)(Lc - T) * 8;
+#if MCMC_SMEM_LEAD2_E
+    double8_t r1 = smem_row8(rowBase, T - 1);
+#endif
 #endif
 #pragma unroll
     for (int u = 0; u < T; ++u) {
-#if MCMC_SMEM_TABLE
+#if MCMC_SMEM_TABLE && MCMC_SMEM_LEAD2_E
+        const double8_t rnext = r1;
+        r1 = smem_row8(rowBase, T - 2 - u);
+#elif MCMC_SMEM_TABLE
         const double8_t rnext = smem_row8(rowBase, T - 1 - u);
 #else
         const double8_t rnext = lds_row8(Rpos, Lc - u - 1);
