@@ -725,7 +725,7 @@ public:
             be->derive(1, rec.finalParams.data(), curves.data());
             st.disease()->set_derived(curves.data());
         }
-        if (writeSamplesToDisk) write_samples(*be);
+        if (writeSamplesToDisk) write_samples(*be, "chainweight ");                   /* mcmc.h:1018 */
         std::cout << "\nThe final acceptance rate was " << (double)rec.nAccept / std::max(nBurnin + nSamples, 1)
                   << "." << std::endl;                                                        /* mcmc.h:1136 */
     }
@@ -751,7 +751,7 @@ public:
         haveSamples = true;
         if (writeSamplesToDisk) {
             std::unique_ptr<Backend> be = eval_state()->backend(target->spec());
-            write_samples(*be);
+            write_samples(*be, "chainweight = ");                                            /* mcmc.h:1167 */
         }
     }
 
@@ -820,11 +820,11 @@ private:
     State* eval_state() const { return evalState ? evalState.get() : (target ? target->state.get() : nullptr); }
 
     /* text dump in the reference's format (mcmc.h:1013-1019, 1047-1059, 1163-1184) */
-    void write_samples(Backend& be) {
+    void write_samples(Backend& be, const char* head) {
         std::stringstream filename;
         filename << "samples" << id << ".txt";
         std::ofstream file(filename.str());
-        file << "chainweight = " << weight << "\n\n";
+        file << head << weight << "\n\n";
         std::shared_ptr<State> work = eval_state()->deep_copy();
         const size_t n = rec.ics.size(), d = be.dim(), no = be.n_out();
         if (n == 0) return;

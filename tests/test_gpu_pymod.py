@@ -92,6 +92,41 @@ def test_chain_run_equals_oracle_chain(cooling):
     assert np.array_equal(chain.get_samples("betaHigh"), samples[2:, -2:-1])
 
 
+def test_text_dump_of_run_and_reevaluate(tmp_path, monkeypatch):
+    """samples<id>.txt: "chainweight w" from run (mcmc.h:1018), "chainweight = w" from
+    reevaluate (mcmc.h:1167); then per saved point "weight w loglike l" and one
+    "name v v ..." line per coordinate in std::map order (mcmc.h:1050-1058)."""
+    data, p, ds, state, target, cfg, m, tgt = _setup(T=1.0)
+    x0 = CC.initial_params(cfg)
+    monkeypatch.chdir(tmp_path)
+    chain = mcmc.Chain(target, 7)
+    chain.writeSamplesToDisk = True
+    chain.run(20, 0, 2, 5)
+    oc = O.OracleChain(m, 7, x0)
+    ll, samples, _ = oc.run(tgt, 20, 0, 2, 5, record=True)
+
+    def blocks(txt):
+        head, *rest = txt.strip().split("\n\n")
+        return head, [b.split("\n") for b in rest]
+
+    head, bl = blocks(open(tmp_path / "samples7.txt").read())
+    assert head == "chainweight 1"
+    assert len(bl) == len(ll)
+    names = sorted(ds.get_names())
+    for b, l, x in zip(bl, ll, samples):
+        w = b[0].split()
+        assert w[0] == "weight" and float(w[1]) == 1 and w[2] == "loglike"
+        assert float(w[3]) == pytest.approx(l, rel=1e-5)              # operator<< prints 6 digits
+        assert [line.split()[0] for line in b[1:]] == names
+        row = {line.split()[0]: np.array(line.split()[1:], dtype=float) for line in b[1:]}
+        assert row["delay"][0] == pytest.approx(x[-1], rel=1e-5)
+        assert len(row["dead"]) == cfg["size"] and len(row["behavior"]) == cfg["nB"]
+        assert np.allclose(row["dead"], m.eval(x, curves=True)[1][7], rtol=1e-5, atol=1e-300)
+    chain.reevaluate(state, 1)
+    head, bl = blocks(open(tmp_path / "samples7.txt").read())
+    assert head == "chainweight = 1" and len(bl) == len(ll) - 1
+
+
 def test_chain_manager_runs_all_chains_in_one_batch(tmp_path, monkeypatch):
     data, p, ds, state, target, cfg, m, tgt = _setup(T=1.0)
     x0 = CC.initial_params(cfg)
