@@ -164,6 +164,7 @@ def main():
     cpu_start = (s.params()[:n_keep].copy(), s.stepsizes()[:n_keep].copy()) if rank == 0 else None
     s.pair_count(reset=True)
     t_before = s.last_timing()
+    diag_before = s.diagnostics()                        # additive sums of this shard (untimed)
     sync()
     t0 = time.perf_counter()
     if args.ladder:
@@ -179,6 +180,13 @@ def main():
         tt = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # cross-chain diagnostics: the additive vector of every shard, summed over the
+    # ranks with ONE all-reduce (RCCL under nccl) -- outside the timed region, not on the data path
+    from mcmc_amd.sharding import allreduce_sum
+    diag_after = s.diagnostics()
+    local = np.concatenate([[diag_after[0] - diag_before[0], float(n_chains)], diag_after[2:]])
+    tot = allreduce_sum(local)
 
     if rank == 0:
         total_steps = world * n_chains * args.steps
@@ -218,6 +226,16 @@ def main():
                          "algorithmic_flops_per_launch": flops / max(launches, 1),
                          "frac_of_fp32_vector_peak": achieved / PEAK_FP32_VECTOR_TFLOPS},
         }
+        n_all, dim = tot[1], cfg["dim"]
+
+        def mean_sd(k):                                   # cross-chain mean / sd from (sum x, sum x^2)
+            mu = tot[k] / n_all
+            return [float(mu), float(np.sqrt(max(tot[k + 1] / n_all - mu * mu, 0.0)))]
+        out["diagnostics"] = {"chains": int(n_all), "ranks": world, "acceptance_timed_steps": float(tot[0] / (n_all * args.steps)),
+                              "loglike_mean_sd": mean_sd(2),
+                              **{nm: mean_sd(4 + 2 * (dim - 3 + j)) for j, nm in enumerate(["betaMild_mean_sd", "betaHigh_mean_sd", "delay_mean_sd"])},
+                              "how": f"mcmc_hip_diagnostics per rank, one all-reduce(SUM) of {len(local)} doubles "
+                                     f"({'RCCL' if (dist is not None and args.backend == 'nccl') else 'single rank' if dist is None else 'gloo'})"}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(cfg, R, cpu_start[0], cpu_start[1], args.contract)
             out["cpu_baseline"] = cb

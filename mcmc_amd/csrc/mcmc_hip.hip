@@ -14,6 +14,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -49,6 +51,13 @@ int fail(int code, const char* fmt, ...) {
                         __FILE__, __LINE__);                                                 \
     } while (0)
 
+/* No exception crosses the C ABI: every entry point with a body that can allocate host
+ * memory is a function-try-block ending in this handler. */
+#define MCMC_ABI_GUARD                                                                           \
+    catch (const std::bad_alloc&) { return fail(MCMC_HIP_ENOMEM, "out of host memory"); }        \
+    catch (const std::exception& e_) { return fail(MCMC_HIP_EHIP, "unexpected exception: %s", e_.what()); } \
+    catch (...) { return fail(MCMC_HIP_EHIP, "unexpected exception"); }
+
 template <typename Tp>
 struct DevBuf {
     Tp* p = nullptr;
@@ -71,7 +80,7 @@ struct mcmc_hip_ctx {
     mcmc_covid_config cfg{};
     std::vector<int32_t> discDays;
     std::vector<uint8_t> discFixed;
-    int device = 0;
+    int device = 0, nCU = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int size = 0, nB = 0, dim = 0, simDays = 0, simPad = 0, nLag = 0, tabRows = 0, histRows = 0;
@@ -244,9 +253,7 @@ int launch_chain_kernel(mcmc_hip_ctx* c, K kernel, bool derive, int T, Args... a
     size_t shmem = lds_bytes(c->M, derive, T);
     if (shmem > kLdsMax)
         return fail(MCMC_HIP_EINVAL, "the series is too long for the LDS image (%zu B > %zu B)", shmem, kLdsMax);
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-    if (grid <= (unsigned)prop.multiProcessorCount && shmem < kLdsSolo) shmem = kLdsSolo;
+    if (grid <= (unsigned)c->nCU && shmem < kLdsSolo) shmem = kLdsSolo;
     HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(MCMC_BLOCK), shmem, c->stream, args...);
     HIP_TRY(hipGetLastError());
@@ -331,18 +338,18 @@ extern "C" {
 
 const char* mcmc_hip_last_error(void) { return g_err.c_str(); }
 
-int mcmc_hip_device_count(void) {
+int mcmc_hip_device_count(void) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
-}
+} MCMC_ABI_GUARD
 
 void mcmc_host_default_disease_params(mcmc_disease_params* p) {
     if (!p) return;
     *p = mcmc_disease_params{4, 2, 0.1, 0.08, 0.004, 0.2, 0.3, 10, 5, 8, 3, 10, 5, 9, 5};
 }
 
-int mcmc_host_make_response_tables(const mcmc_disease_params* p, uint64_t n_traj, int32_t n_lag, double* R) {
+int mcmc_host_make_response_tables(const mcmc_disease_params* p, uint64_t n_traj, int32_t n_lag, double* R) try {
     if (!p || !R || n_lag < 1 || n_lag > MCMC_HIP_TRAJ_NDAYS || n_traj == 0)
         return fail(MCMC_HIP_EINVAL, "make_response_tables: bad arguments");
     Trajectories tr;
@@ -359,10 +366,10 @@ int mcmc_host_make_response_tables(const mcmc_disease_params* p, uint64_t n_traj
         }
     }
     return 0;
-}
+} MCMC_ABI_GUARD
 
 int mcmc_host_perturb_ics(const double* x0, int32_t dim, int64_t n_chains, double a, uint64_t initstate,
-                          uint64_t initseq, double* out) {
+                          uint64_t initseq, double* out) try {
     if (!x0 || !out || dim < 1 || n_chains < 0) return fail(MCMC_HIP_EINVAL, "perturb_ics: bad arguments");
     HostPcg r;
     pcg32_seed(r.state, r.inc, initstate, initseq);
@@ -370,7 +377,7 @@ int mcmc_host_perturb_ics(const double* x0, int32_t dim, int64_t n_chains, doubl
         for (int k = 0; k < dim; ++k)
             out[c * dim + k] = x0[k] + (r.next_float() - .5f) * x0[k] * a;   /* mcmc.h:310 */
     return 0;
-}
+} MCMC_ABI_GUARD
 
 int32_t mcmc_hip_n_saved(int32_t n_samples, int32_t n_burnin, int32_t n_adjust, int32_t thinning) {
     if (thinning < 1) return 0;
@@ -380,7 +387,9 @@ int32_t mcmc_hip_n_saved(int32_t n_samples, int32_t n_burnin, int32_t n_adjust, 
     return n;
 }
 
-int mcmc_hip_create(const mcmc_covid_config* cfg, int device, mcmc_hip_ctx** out) {
+static int init_ctx(mcmc_hip_ctx* c, const mcmc_covid_config* cfg, int device);
+
+int mcmc_hip_create(const mcmc_covid_config* cfg, int device, mcmc_hip_ctx** out) try {
     if (!cfg || !out) return fail(MCMC_HIP_EINVAL, "create: null argument");
     *out = nullptr;
     if (cfg->n_data < 2 || cfg->max_delay < 1 || cfg->n_predict < 0)
@@ -400,12 +409,22 @@ int mcmc_hip_create(const mcmc_covid_config* cfg, int device, mcmc_hip_ctx** out
 
     mcmc_hip_ctx* c = new (std::nothrow) mcmc_hip_ctx();
     if (!c) return fail(MCMC_HIP_ENOMEM, "out of host memory");
+    int r;
+    try { r = init_ctx(c, cfg, device); } catch (...) { mcmc_hip_destroy(c); throw; }
+    if (r) { mcmc_hip_destroy(c); return r; }
+    *out = c;
+    return 0;
+} MCMC_ABI_GUARD
+
+/* second half of mcmc_hip_create: everything that can fail once the context exists */
+static int init_ctx(mcmc_hip_ctx* c, const mcmc_covid_config* cfg, int device) {
     c->cfg = *cfg;
     c->discDays.assign(cfg->disc_days, cfg->disc_days + cfg->n_disc);
     c->discFixed.assign(cfg->disc_fixed, cfg->disc_fixed + cfg->n_disc);
     c->cfg.disc_days = c->discDays.data();
     c->cfg.disc_fixed = c->discFixed.data();
     c->device = device;
+    HIP_TRY(hipDeviceGetAttribute(&c->nCU, hipDeviceAttributeMultiprocessorCount, device));
     { const char* e = std::getenv("MCMC_HIP_COOP"); c->coop = e && std::atoi(e) != 0; }
     c->size = cfg->max_delay + cfg->n_predict + cfg->n_data;          /* covid.h:297 */
     c->nB = cfg->n_data - cfg->fix_behavior_in_advance;               /* covid.h:299 */
@@ -416,7 +435,7 @@ int mcmc_hip_create(const mcmc_covid_config* cfg, int device, mcmc_hip_ctx** out
     c->tabRows = c->size + 3 * MCMC_T;
     c->histRows = c->size + 4 * MCMC_T + MCMC_HOFF(MCMC_T);
 
-    auto cleanup = [&](int r) { mcmc_hip_destroy(c); return r; };
+    auto cleanup = [](int r) { return r; };            /* the caller destroys the context on failure */
     if (hipStreamCreate(&c->stream) != hipSuccess) return cleanup(fail(MCMC_HIP_EHIP, "hipStreamCreate failed"));
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
         return cleanup(fail(MCMC_HIP_EHIP, "hipEventCreate failed"));
@@ -454,11 +473,10 @@ int mcmc_hip_create(const mcmc_covid_config* cfg, int device, mcmc_hip_ctx** out
     M.discThr = 2 / nNotFixed;                                        /* covid.h:581 (+inf if none fixed) */
     M.discFixedMask = mask;
     M.capacity = c->dCapacity.p; M.seg = c->dSeg.p;
-    *out = c;
     return 0;
 }
 
-int mcmc_hip_destroy(mcmc_hip_ctx* c) {
+int mcmc_hip_destroy(mcmc_hip_ctx* c) try {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -467,9 +485,9 @@ int mcmc_hip_destroy(mcmc_hip_ctx* c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
-}
+} MCMC_ABI_GUARD
 
-int mcmc_hip_set_tables(mcmc_hip_ctx* c, const double* R, int32_t n_lag) {
+int mcmc_hip_set_tables(mcmc_hip_ctx* c, const double* R, int32_t n_lag) try {
     if (int r = check_ctx(c)) return r;
     if (!R) return fail(MCMC_HIP_EINVAL, "set_tables: null table");
     if (n_lag < c->nLag) return fail(MCMC_HIP_EINVAL, "set_tables: n_lag=%d but the model needs %d lags", n_lag, c->nLag);
@@ -489,9 +507,9 @@ int mcmc_hip_set_tables(mcmc_hip_ctx* c, const double* R, int32_t n_lag) {
     c->M.Rneg = c->dRneg.p;
     c->haveTables = true;
     return 0;
-}
+} MCMC_ABI_GUARD
 
-int mcmc_hip_set_data(mcmc_hip_ctx* c, const double* deaths, const double* sigma) {
+int mcmc_hip_set_data(mcmc_hip_ctx* c, const double* deaths, const double* sigma) try {
     if (int r = check_ctx(c)) return r;
     if (!deaths || !sigma) return fail(MCMC_HIP_EINVAL, "set_data: null series");
     HIP_TRY(hipSetDevice(c->device));
@@ -506,7 +524,7 @@ int mcmc_hip_set_data(mcmc_hip_ctx* c, const double* deaths, const double* sigma
     c->M.sigma2 = c->dSigma2.p;
     c->haveData = true;
     return 0;
-}
+} MCMC_ABI_GUARD
 
 static int alloc_work(mcmc_hip_ctx* c, long long nP) {
     /* history + LL scratch for nP lanes; contents are fully rewritten by every evaluation */
@@ -522,7 +540,7 @@ static int alloc_work(mcmc_hip_ctx* c, long long nP) {
 }
 
 int mcmc_hip_set_chains(mcmc_hip_ctx* c, int64_t n_chains, const double* params, const double* stepsizes,
-                        const uint64_t* chain_ids, uint64_t first_chain_id) {
+                        const uint64_t* chain_ids, uint64_t first_chain_id) try {
     if (int r = check_ctx(c)) return r;
     if (!c->haveTables || !c->haveData) return fail(MCMC_HIP_ESTATE, "set_chains: call set_tables and set_data first");
     if (n_chains < 1 || !params) return fail(MCMC_HIP_EINVAL, "set_chains: need n_chains >= 1 and params");
@@ -577,9 +595,9 @@ int mcmc_hip_set_chains(mcmc_hip_ctx* c, int64_t n_chains, const double* params,
     c->haveChains = true;
     c->stepsDone = 0;
     return 0;
-}
+} MCMC_ABI_GUARD
 
-int mcmc_hip_step(mcmc_hip_ctx* c, int32_t n_steps, double beta, int32_t random_subspace) {
+int mcmc_hip_step(mcmc_hip_ctx* c, int32_t n_steps, double beta, int32_t random_subspace) try {
     if (int r = check_ctx(c)) return r;
     if (!c->haveChains) return fail(MCMC_HIP_ESTATE, "step: call set_chains first");
     if (n_steps < 0) return fail(MCMC_HIP_EINVAL, "step: n_steps < 0");
@@ -587,10 +605,10 @@ int mcmc_hip_step(mcmc_hip_ctx* c, int32_t n_steps, double beta, int32_t random_
     std::vector<double> betas(n_steps, beta);
     std::vector<int> flags(n_steps, random_subspace ? SF_RANDOM : 0);
     return run_schedule(c, betas, flags, 0, (size_t)n_steps, MCMC_STEPS_PER_LAUNCH, nullptr);
-}
+} MCMC_ABI_GUARD
 
 /* ---- tempering ladder (extension) ---- */
-int mcmc_hip_set_ladder(mcmc_hip_ctx* c, int32_t n_temps, const double* temps, uint64_t swap_seed, uint64_t first_ladder) {
+int mcmc_hip_set_ladder(mcmc_hip_ctx* c, int32_t n_temps, const double* temps, uint64_t swap_seed, uint64_t first_ladder) try {
     if (int r = check_ctx(c)) return r;
     if (!c->haveChains) return fail(MCMC_HIP_ESTATE, "set_ladder: call set_chains first");
     if (n_temps == 0) { c->S.chainBeta = nullptr; c->ladderK = 0; c->nLadders = 0; return 0; }
@@ -624,9 +642,9 @@ int mcmc_hip_set_ladder(mcmc_hip_ctx* c, int32_t n_temps, const double* temps, u
     c->ladderK = K; c->nLadders = nL;
     c->swapRounds[0] = c->swapRounds[1] = 0;
     return 0;
-}
+} MCMC_ABI_GUARD
 
-int mcmc_hip_swap(mcmc_hip_ctx* c, int32_t parity) {
+int mcmc_hip_swap(mcmc_hip_ctx* c, int32_t parity) try {
     if (int r = check_ctx(c)) return r;
     if (!c->haveChains || c->ladderK < 2) return fail(MCMC_HIP_ESTATE, "swap: call set_ladder first");
     if (parity != 0 && parity != 1) return fail(MCMC_HIP_EINVAL, "swap: parity must be 0 or 1");
@@ -639,9 +657,9 @@ int mcmc_hip_swap(mcmc_hip_ctx* c, int32_t parity) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->swapRounds[parity] += 1;
     return 0;
-}
+} MCMC_ABI_GUARD
 
-int mcmc_hip_run_tempered(mcmc_hip_ctx* c, int32_t n_rounds, int32_t steps_per_round) {
+int mcmc_hip_run_tempered(mcmc_hip_ctx* c, int32_t n_rounds, int32_t steps_per_round) try {
     if (int r = check_ctx(c)) return r;
     if (!c->haveChains || c->ladderK < 2) return fail(MCMC_HIP_ESTATE, "run_tempered: call set_ladder first");
     if (n_rounds < 0 || steps_per_round < 0) return fail(MCMC_HIP_EINVAL, "run_tempered: negative count");
@@ -650,18 +668,18 @@ int mcmc_hip_run_tempered(mcmc_hip_ctx* c, int32_t n_rounds, int32_t steps_per_r
         if (int r = mcmc_hip_swap(c, k & 1)) return r;
     }
     return 0;
-}
+} MCMC_ABI_GUARD
 
-int mcmc_hip_get_rungs(mcmc_hip_ctx* c, int32_t* out) {
+int mcmc_hip_get_rungs(mcmc_hip_ctx* c, int32_t* out) try {
     if (int r = check_ctx(c)) return r;
     if (!c->haveChains || c->ladderK < 2) return fail(MCMC_HIP_ESTATE, "get_rungs: call set_ladder first");
     if (!out) return fail(MCMC_HIP_EINVAL, "null output buffer");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpy(out, c->dRungOf.p, c->nChains * sizeof(int32_t), hipMemcpyDeviceToHost));
     return 0;
-}
+} MCMC_ABI_GUARD
 
-int mcmc_hip_get_swap_counts(mcmc_hip_ctx* c, int64_t* accepted, int64_t* proposed) {
+int mcmc_hip_get_swap_counts(mcmc_hip_ctx* c, int64_t* accepted, int64_t* proposed) try {
     if (int r = check_ctx(c)) return r;
     if (!c->haveChains || c->ladderK < 2) return fail(MCMC_HIP_ESTATE, "get_swap_counts: call set_ladder first");
     if (!accepted || !proposed) return fail(MCMC_HIP_EINVAL, "null output buffer");
@@ -673,10 +691,10 @@ int mcmc_hip_get_swap_counts(mcmc_hip_ctx* c, int64_t* accepted, int64_t* propos
         proposed[r] = (int64_t)(c->swapRounds[r & 1] * (unsigned long long)c->nLadders);
     }
     return 0;
-}
+} MCMC_ABI_GUARD
 
 int mcmc_hip_run(mcmc_hip_ctx* c, int32_t nSamples, int32_t nBurnin, int32_t nAdjust, int32_t thinning,
-                 int32_t record_samples, int32_t compute_mean) {
+                 int32_t record_samples, int32_t compute_mean) try {
     if (int r = check_ctx(c)) return r;
     if (!c->haveChains) return fail(MCMC_HIP_ESTATE, "run: call set_chains first");
     if (nSamples < 0 || nBurnin < 0 || nAdjust < 0 || thinning < 1)
@@ -740,7 +758,7 @@ int mcmc_hip_run(mcmc_hip_ctx* c, int32_t nSamples, int32_t nBurnin, int32_t nAd
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->nSaved = nSaved;
     return 0;
-}
+} MCMC_ABI_GUARD
 
 int mcmc_hip_dim(const mcmc_hip_ctx* c) { return c ? c->dim : MCMC_HIP_EINVAL; }
 int mcmc_hip_size(const mcmc_hip_ctx* c) { return c ? c->size : MCMC_HIP_EINVAL; }
@@ -792,54 +810,58 @@ static int gather_soa(mcmc_hip_ctx* c, const double* src, double* out) {
     return 0;
 }
 
-int mcmc_hip_get_params(mcmc_hip_ctx* c, double* out) {
+int mcmc_hip_get_params(mcmc_hip_ctx* c, double* out) try {
     if (int r = need_chains(c, out)) return r;
     return gather_soa(c, c->S.params, out);
-}
-int mcmc_hip_get_loglike(mcmc_hip_ctx* c, double* out) {
+} MCMC_ABI_GUARD
+int mcmc_hip_get_loglike(mcmc_hip_ctx* c, double* out) try {
     if (int r = need_chains(c, out)) return r;
     return copy_field<double>(c, c->S.ll, 2, out);
-}
-int mcmc_hip_get_stepsizes(mcmc_hip_ctx* c, double* out) {
+} MCMC_ABI_GUARD
+int mcmc_hip_get_stepsizes(mcmc_hip_ctx* c, double* out) try {
     if (int r = need_chains(c, out)) return r;
     return copy_field<double>(c, c->S.stepsize, 1, out);
-}
-int mcmc_hip_get_accept_counts(mcmc_hip_ctx* c, int32_t* out) {
+} MCMC_ABI_GUARD
+int mcmc_hip_get_accept_counts(mcmc_hip_ctx* c, int32_t* out) try {
     if (int r = need_chains(c, out)) return r;
     return copy_field<int>(c, c->S.nAccept, 1, out);
-}
-int mcmc_hip_get_rng_state(mcmc_hip_ctx* c, uint64_t* out) {
+} MCMC_ABI_GUARD
+int mcmc_hip_get_rng_state(mcmc_hip_ctx* c, uint64_t* out) try {
     if (int r = need_chains(c, out)) return r;
     return copy_field<uint64_t>(c, c->S.rng, 2, out);
-}
-int mcmc_hip_get_loglikes(mcmc_hip_ctx* c, double* out) {
+} MCMC_ABI_GUARD
+int mcmc_hip_get_loglikes(mcmc_hip_ctx* c, double* out) try {
     if (int r = need_chains(c, out)) return r;
     if (c->nSaved == 0) return fail(MCMC_HIP_ESTATE, "Requested loglikes, but none are present");
     return copy_rows<double>(c, c->S.recLL, c->nSaved, out);
-}
-int mcmc_hip_get_samples(mcmc_hip_ctx* c, int64_t chain, int32_t coord_first, int32_t coord_count, double* out) {
+} MCMC_ABI_GUARD
+int mcmc_hip_get_samples(mcmc_hip_ctx* c, int64_t chain, int32_t coord_first, int32_t coord_count, double* out) try {
     if (int r = need_chains(c, out)) return r;
     if (!c->recSamples || c->nSaved == 0) return fail(MCMC_HIP_ESTATE, "Requested samples, but none are present");
     if (chain < 0 || chain >= c->nChains || coord_first < 0 || coord_count < 1 || coord_first + coord_count > c->dim)
         return fail(MCMC_HIP_EINVAL, "get_samples: chain/coordinate range out of bounds");
-    const size_t tile = (size_t)(chain / MCMC_WAVE), lane = (size_t)(chain % MCMC_WAVE);
-    /* strided device->host copy: element (s,k) sits at ((s*nTiles + tile)*dim + k)*64 + lane */
-    for (int s = 0; s < c->nSaved; ++s)
-        HIP_TRY(hipMemcpy2D(out + (size_t)s * coord_count, sizeof(double),
-                            c->S.recSamples + (((size_t)s * c->nTiles + tile) * c->dim + coord_first) * MCMC_WAVE + lane,
-                            (size_t)MCMC_WAVE * sizeof(double), sizeof(double), coord_count, hipMemcpyDeviceToHost));
+    /* element (s,k) sits at ((s*nTiles + tile)*dim + k)*64 + lane: gathered on the device, one copy out */
+    const long long count = (long long)c->nSaved * coord_count;
+    DevBuf<double> stage;
+    if (int r = stage.alloc((size_t)count)) return r;
+    hipLaunchKernelGGL(chain_samples_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream,
+                       (const double*)c->S.recSamples, stage.p, c->nSaved, c->nTiles, c->dim, (long long)(chain / MCMC_WAVE),
+                       (int)(chain % MCMC_WAVE), (int)coord_first, (int)coord_count);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, stage.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
-}
-int mcmc_hip_get_sample_all(mcmc_hip_ctx* c, int32_t saved_index, double* out) {
+} MCMC_ABI_GUARD
+int mcmc_hip_get_sample_all(mcmc_hip_ctx* c, int32_t saved_index, double* out) try {
     if (int r = need_chains(c, out)) return r;
     if (!c->recSamples || saved_index < 0 || saved_index >= c->nSaved)
         return fail(MCMC_HIP_EINVAL, "get_sample_all: no such saved sample");
     return gather_soa(c, c->S.recSamples + (size_t)saved_index * c->dim * c->nP, out);
-}
-int mcmc_hip_get_mean(mcmc_hip_ctx* c, double* out) {
+} MCMC_ABI_GUARD
+int mcmc_hip_get_mean(mcmc_hip_ctx* c, double* out) try {
     if (int r = need_chains(c, out)) return r;
     return gather_soa(c, c->dMean.p, out);
-}
+} MCMC_ABI_GUARD
 
 /* shared by eval and derive: external vectors on their own lane set */
 static int with_external(mcmc_hip_ctx* c, int64_t n, const double* params, bool derive, double* out) {
@@ -851,7 +873,7 @@ static int with_external(mcmc_hip_ctx* c, int64_t n, const double* params, bool 
     const int dim = c->dim;
     /* a temporary lane set so that chain state is untouched */
     mcmc_hip_ctx tmp;
-    tmp.cfg = c->cfg; tmp.device = c->device; tmp.stream = c->stream; tmp.size = c->size;
+    tmp.cfg = c->cfg; tmp.device = c->device; tmp.nCU = c->nCU; tmp.stream = c->stream; tmp.size = c->size;
     tmp.simPad = c->simPad; tmp.histRows = c->histRows; tmp.dim = dim; tmp.nP = nP; tmp.nChains = n;
     tmp.M = c->M; tmp.nTiles = (int)(nP / MCMC_WAVE);
     int rc = 0;
@@ -887,14 +909,14 @@ static int with_external(mcmc_hip_ctx* c, int64_t n, const double* params, bool 
     return rc;
 }
 
-int mcmc_hip_eval(mcmc_hip_ctx* c, int64_t n, const double* params, double* ll_out) {
+int mcmc_hip_eval(mcmc_hip_ctx* c, int64_t n, const double* params, double* ll_out) try {
     return with_external(c, n, params, false, ll_out);
-}
-int mcmc_hip_derive(mcmc_hip_ctx* c, int64_t n, const double* params, double* curves_out) {
+} MCMC_ABI_GUARD
+int mcmc_hip_derive(mcmc_hip_ctx* c, int64_t n, const double* params, double* curves_out) try {
     return with_external(c, n, params, true, curves_out);
-}
+} MCMC_ABI_GUARD
 
-int mcmc_hip_diagnostics(mcmc_hip_ctx* c, double* out) {
+int mcmc_hip_diagnostics(mcmc_hip_ctx* c, double* out) try {
     if (int r = need_chains(c, out)) return r;
     const int len = 4 + 2 * c->dim;
     DevBuf<double> d;
@@ -906,19 +928,19 @@ int mcmc_hip_diagnostics(mcmc_hip_ctx* c, double* out) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     out[1] = (double)c->stepsDone;
     return 0;
-}
+} MCMC_ABI_GUARD
 
 int mcmc_hip_last_timing(mcmc_hip_ctx* c, double* adjust_s, double* sampling_s, double* step_kernel_s,
-                         int64_t* step_kernel_launches) {
+                         int64_t* step_kernel_launches) try {
     if (int r = check_ctx(c)) return r;
     if (adjust_s) *adjust_s = c->adjustS;
     if (sampling_s) *sampling_s = c->samplingS;
     if (step_kernel_s) *step_kernel_s = c->kernelS;
     if (step_kernel_launches) *step_kernel_launches = c->kernelLaunches;
     return 0;
-}
+} MCMC_ABI_GUARD
 
-int mcmc_hip_debug_phase_cycles(mcmc_hip_ctx* c, double* out, int32_t reset) {
+int mcmc_hip_debug_phase_cycles(mcmc_hip_ctx* c, double* out, int32_t reset) try {
     if (int r = check_ctx(c)) return r;
     if (!out) return fail(MCMC_HIP_EINVAL, "null output buffer");
     HIP_TRY(hipSetDevice(c->device));
@@ -930,9 +952,9 @@ int mcmc_hip_debug_phase_cycles(mcmc_hip_ctx* c, double* out, int32_t reset) {
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), h, sizeof(h)));
     }
     return 0;
-}
+} MCMC_ABI_GUARD
 
-int mcmc_hip_pair_count(mcmc_hip_ctx* c, double* pairs_out, int32_t reset) {
+int mcmc_hip_pair_count(mcmc_hip_ctx* c, double* pairs_out, int32_t reset) try {
     if (int r = need_chains(c, pairs_out)) return r;
     std::vector<unsigned long long> h(c->nP);
     HIP_TRY(hipMemcpy(h.data(), c->S.pairs, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -941,21 +963,21 @@ int mcmc_hip_pair_count(mcmc_hip_ctx* c, double* pairs_out, int32_t reset) {
     *pairs_out = s;
     if (reset) HIP_TRY(hipMemset(c->S.pairs, 0, h.size() * sizeof(unsigned long long)));
     return 0;
-}
+} MCMC_ABI_GUARD
 
 /* ------------------------------------------------------------------ toy targets ---- */
 static int toy_dim(int kind) { return kind == MCMC_TOY_MYLIKE1 ? 3 : kind == MCMC_TOY_FOURGAUSS ? 2 : -1; }
 static int toy_n_out(int kind) { return kind == MCMC_TOY_MYLIKE1 ? 4 : kind == MCMC_TOY_FOURGAUSS ? 2 : -1; }
 
-int mcmc_hip_toy_dim(int32_t kind) {
+int mcmc_hip_toy_dim(int32_t kind) try {
     const int d = toy_dim(kind);
     return d > 0 ? d : fail(MCMC_HIP_EINVAL, "unknown toy target %d", kind);
-}
+} MCMC_ABI_GUARD
 
-int mcmc_hip_toy_n_out(int32_t kind) {
+int mcmc_hip_toy_n_out(int32_t kind) try {
     const int d = toy_n_out(kind);
     return d > 0 ? d : fail(MCMC_HIP_EINVAL, "unknown toy target %d", kind);
-}
+} MCMC_ABI_GUARD
 
 static int toy_device(int device) {
     int ndev = 0;
@@ -966,7 +988,7 @@ static int toy_device(int device) {
     return 0;
 }
 
-int mcmc_hip_toy_eval(int device, int32_t kind, double difficulty, int64_t n, const double* x, double* ll_out) {
+int mcmc_hip_toy_eval(int device, int32_t kind, double difficulty, int64_t n, const double* x, double* ll_out) try {
     const int dim = toy_dim(kind);
     if (dim < 0 || n < 1 || !x || !ll_out) return fail(MCMC_HIP_EINVAL, "toy_eval: bad arguments");
     if (int r = toy_device(device)) return r;
@@ -983,13 +1005,13 @@ int mcmc_hip_toy_eval(int device, int32_t kind, double difficulty, int64_t n, co
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(ll_out, dl.p, n * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
-}
+} MCMC_ABI_GUARD
 
 int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target_kind, double target_T,
                      double target_slope, double target_Tinit, int64_t n, const uint64_t* chain_ids,
                      uint64_t first_chain_id, double* x, double* stepsizes, int32_t nSamples, int32_t nBurnin,
                      int32_t nAdjust, int32_t thinning, double* loglikes_out, double* samples_out,
-                     double* mean_out, int32_t* n_accept_out) {
+                     double* mean_out, int32_t* n_accept_out) try {
     const int dim = toy_dim(kind), nOut = toy_n_out(kind);
     if (dim < 0 || n < 1 || !x || !stepsizes) return fail(MCMC_HIP_EINVAL, "toy_run: bad arguments");
     if (nSamples < 0 || nBurnin < 0 || nAdjust < 0 || thinning < 1)
@@ -1058,6 +1080,6 @@ int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target
             for (int k = 0; k < nOut; ++k) mean_out[(size_t)c * nOut + k] = h[(size_t)k * n + c];
     }
     return 0;
-}
+} MCMC_ABI_GUARD
 
 }  // extern "C"

@@ -1515,6 +1515,17 @@ __global__ void tile_out_kernel(const Tp* __restrict__ src, Tp* __restrict__ dst
     const Tp* s = src + (chain / MCMC_WAVE) * rows * MCMC_WAVE + chain % MCMC_WAVE;
     for (int k = 0; k < rows; ++k) dst[chain * rows + k] = s[(long long)k * MCMC_WAVE];
 }
+/* the recorded points of ONE chain, coordinates [coordFirst, coordFirst+coordCount), out of the
+ * tile-major record [slot][tile][dim][64] as a dense [nSaved][coordCount] block */
+__global__ void chain_samples_kernel(const double* __restrict__ rec, double* __restrict__ out, int nSaved, int nTiles,
+                                     int dim, long long tile, int lane, int coordFirst, int coordCount) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nSaved * coordCount) return;
+    const long long s = i / coordCount;
+    const int k = (int)(i % coordCount);
+    out[i] = rec[((s * nTiles + tile) * dim + coordFirst + k) * MCMC_WAVE + lane];
+}
+
 __global__ void scale_kernel(double* __restrict__ a, long long count, double f) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) a[i] *= f;
