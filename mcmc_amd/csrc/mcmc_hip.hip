@@ -498,6 +498,7 @@ int mcmc_hip_set_tables(mcmc_hip_ctx* c, const double* R, int32_t n_lag) try {
     for (int d = 0; d < c->nLag; ++d) {
         for (int k = 0; k < 7; ++k) pos[(size_t)d * 8 + k] = R[(size_t)k * n_lag + d];
         for (int k = 0; k < 3; ++k) neg[(size_t)d * 4 + k] = R[(size_t)(7 + k) * n_lag + d];
+        neg[(size_t)d * 4 + 3] = 1.0;                                /* the flat add() of covid.h:387-391 reaches this lag */
     }
     if (int r = c->dRpos.alloc(pos.size())) return r;
     if (int r = c->dRneg.alloc(neg.size())) return r;

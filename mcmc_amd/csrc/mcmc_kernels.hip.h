@@ -72,7 +72,7 @@ struct DevModel {
     float discThr;                /* 2/nNotFixed, float division done on the host    */
     unsigned discFixedMask;
     const double* Rpos;           /* [tabRows][8]: MI HI INC MILD SER REC DEAD 0; rows >= nLagRows zero */
-    const double* Rneg;           /* [tabRows][4]: SFS RFS DFS 0                     */
+    const double* Rneg;           /* [tabRows][4]: SFS RFS DFS 1; rows >= nLagRows zero */
     const double* capacity;       /* [simPad]                                        */
     const double* deaths;         /* [nData]                                         */
     const double* sigma2;         /* [nData]  sigma[i]*sigma[i] (covid.h:491)        */
@@ -375,7 +375,11 @@ __device__ __forceinline__ void lag_chunk_e(double (&acc)[A_NPOS][T], double (&W
             acc[A_REC][t] = madd<FUSE>(nk, r[5], acc[A_REC][t]);
             acc[A_DEAD][t] = madd<FUSE>(nk, r[6], acc[A_DEAD][t]);
             const double nek = -ek;
-            acc[A_DEAD][t] = acc[A_DEAD][t] + ek;                       /* add(), covid.h:418 */
+            /* add(), covid.h:418 -- like project() it stops after traj.nDays days (covid.h:388):
+             * rn[3] is 1 for the lags below nLagRows and 0 above; fma(ek, 1, acc) IS acc + ek
+             * (the product is exact, one rounding), so this costs nothing and cuts the flat
+             * add off exactly where the reference does */
+            acc[A_DEAD][t] = __builtin_fma(ek, rn[3], acc[A_DEAD][t]);
             acc[A_SER][t] = madd<FUSE>(nek, rn[0], acc[A_SER][t]);      /* covid.h:426 */
             acc[A_REC][t] = madd<FUSE>(nek, rn[1], acc[A_REC][t]);      /* covid.h:427 */
             acc[A_DEAD][t] = madd<FUSE>(nek, rn[2], acc[A_DEAD][t]);    /* covid.h:428 */

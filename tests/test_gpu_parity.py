@@ -126,6 +126,23 @@ def test_long_horizon_beyond_the_trajectory_table(R11, R10):
     s.close()
 
 
+def test_long_horizon_with_capacity_corrections(R11, R10):
+    """The flat add() of the extra deaths stops after traj.nDays = 500 days just like project()
+    (covid.h:387-391): with corrections from day ~49 on and 560 simulated days, the lags 500..510
+    of those source days must contribute nothing -- not even the `+ e`."""
+    cfg = make_cfg(520, R11, cap0=3.0, cap_incr_rate=0.5, initial_beta_mild=1.5, initial_beta_high=4.0)
+    m = O.Model(cfg, R11)
+    xs = perturbed(cfg, 64, 0.05)
+    s = H.CovidSampler(cfg, R10)
+    ll = s.eval(xs)
+    ref = np.array([[m.eval(x), m.prior(x)] for x in xs[:8]])
+    assert np.array_equal(ll[:8], ref) and np.all(np.isfinite(ll))
+    cur = s.derive(xs[:2])
+    refc = np.array([m.eval(x, curves=True)[1] for x in xs[:2]])
+    assert np.array_equal(cur, refc)
+    s.close()
+
+
 @pytest.mark.parametrize("scale", [1.0, 0.25, 8.0, 1.0 / 3.0, 37.3])
 def test_smoothness_prior_scales(R11, R10, scale):
     """dx = L/n of SmoothnessPrior (mcmc.h:201): the kernels multiply by the exact reciprocal when
