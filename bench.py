@@ -36,7 +36,7 @@ CHAINS_PER_GPU = 65536
 BETA_MILD, BETA_HIGH = 0.8, 2.5     # SURVEY 8d's (2, 10) overflow to NaN in the forward model
 
 
-def build_workload(device, n_chains, first_chain_id, contract, n_data=N_DATA):
+def build_workload(device, n_chains, first_chain_id, contract, n_data=N_DATA, precision="f64"):
     """Synthetic inputs per SURVEY 8(d): response table by the host precompute, counts by the
     forward model at the initial parameters, sigma by the notebook's recipe, chains = initial
     parameters perturbed by +-1 % (pcg32(0,0)), chain ids first_chain_id.."""
@@ -57,7 +57,7 @@ def build_workload(device, n_chains, first_chain_id, contract, n_data=N_DATA):
     # one global IC stream so that chain i has the same start on any sharding
     xs_all = H.perturb_ics(x0, first_chain_id - 1 + n_chains, 0.01)
     xs = xs_all[first_chain_id - 1:]
-    sampler = H.CovidSampler(cfg, R, device)
+    sampler = H.CovidSampler(cfg, R, device, precision=precision)
     sampler.set_chains(xs, first_chain_id=first_chain_id)
     return cfg, R, xs, sampler
 
@@ -107,6 +107,33 @@ def ess_leg(cfg, R, device, contract, xs, stepsizes, first_id, n_steps, thinning
                       "positive sequence per chain, summed over chains"}
 
 
+def fast_mode_leg(cfg, R, device, xs, first_id, args):
+    """The same workload in the FAST arithmetic mode (renewal convolution in packed FP32,
+    include/mcmc_hip.h): its own adaptation, warm-up and timed steps.  Reported beside the FP64
+    figure, never as `value` -- it is not the reference's arithmetic."""
+    s = H.CovidSampler(cfg, R, device, precision="f32_model")
+    s.set_chains(xs, first_chain_id=first_id)
+    if args.adjust > 0:
+        s.run(0, 0, args.adjust, 1000000)
+    s.step(args.warmup, 1.0, True)
+    s.pair_count(reset=True)
+    t0 = s.last_timing()
+    w0 = time.perf_counter()
+    s.step(args.steps, 1.0, True)
+    wall = time.perf_counter() - w0
+    t1 = s.last_timing()
+    pairs = s.pair_count()
+    n = xs.shape[0]
+    s.close()
+    ksec, launches = t1["step_kernel_s"] - t0["step_kernel_s"], t1["launches"] - t0["launches"]
+    flops = 16.0 * pairs + (10.0 * N_DATA + 7.0 * cfg["nB"]) * n * args.steps
+    return {"value": n * args.steps / wall, "unit": "MH steps/s", "ms_per_step": 1e3 * wall / args.steps,
+            "dtype": "f32 packed (renewal convolution) + f64 (everything else)",
+            "kernel_ms_per_launch": 1e3 * ksec / max(launches, 1), "achieved": flops / ksec / 1e12,
+            "peak": PEAK_FP32_VECTOR_TFLOPS, "unit_roofline": "TFLOP/s", "frac": flops / ksec / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
+            "parity": "statistical (tests/test_gpu_fast_mode.py), not bit-exact: never the headline value"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +144,7 @@ def main():
     ap.add_argument("--adjust", type=int, default=int(os.environ.get("MCMC_BENCH_ADJUST", "25")),
                     help="adjust-phase iterations (20 MH steps each, mcmc.h:1083-1119) run untimed before the warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-leg", action="store_true", help="skip the FP32 fast-mode leg (N=1 only)")
     ap.add_argument("--ess-chains", type=int, default=4096, help="chains of the ESS leg (0: skip it)")
     ap.add_argument("--ess-steps", type=int, default=2000)
     # BASELINE.json configs[3] (extension): ladders of K temperatures, whole ladders per GPU
@@ -240,6 +268,9 @@ def main():
             cb = cpu_baseline(cfg, R, cpu_start[0], cpu_start[1], args.contract)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = value / cb["value"]
+        if world == 1 and not args.no_fast_leg and not args.ladder and args.contract:
+            out["fp32_fast_mode"] = fast_mode_leg(cfg, R, device, xs, first_id, args)
+            out["fp32_fast_mode"]["speedup_over_f64"] = out["fp32_fast_mode"]["value"] / value
         if world == 1 and args.ess_chains > 0 and not args.ladder:
             ne = min(args.ess_chains, n_chains)
             e = ess_leg(cfg, R, device, args.contract, cpu_start[0][:ne], cpu_start[1][:ne], first_id, args.ess_steps, 5)

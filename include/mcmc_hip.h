@@ -107,6 +107,19 @@ int mcmc_hip_set_tables(mcmc_hip_ctx* ctx, const double* R, int32_t n_lag);
 /* data.deathsPerDay / data.deathsSigma (covid.h:47), each [n_data]. */
 int mcmc_hip_set_data(mcmc_hip_ctx* ctx, const double* deaths, const double* sigma);
 
+/* Arithmetic of the model time-stepper.  No counterpart in the reference, whose only
+ * arithmetic is `using Float = double` (mcmc.h:43) = MCMC_HIP_PRECISION_F64, the default and
+ * the only mode held to bit-exact parity.  MCMC_HIP_PRECISION_F32_MODEL ("fast mode", the FP32
+ * figure north_star asks for) runs the renewal convolution of DiseaseSpread::eval
+ * (covid.h:376-410,426-428) in packed single precision and everything else -- proposal,
+ * capacity test, feedback, likelihood sum, prior, accept -- in double; it needs
+ * cfg.contract = 1 and is held to a statistical bar (tests/test_gpu_fast_mode.py).
+ * Call after set_tables and before set_chains; eval/derive: eval follows the mode, derive is
+ * always double. */
+#define MCMC_HIP_PRECISION_F64        0
+#define MCMC_HIP_PRECISION_F32_MODEL  1
+int mcmc_hip_set_precision(mcmc_hip_ctx* ctx, int32_t mode);
+
 /* Replaces ChainManager's per-chain setup loop (mcmc.h:1517-1532): n chains, chain i has
  * RNG pcg32(0, chain_ids[i]) (mcmc.h:999,1527) and parameters params[i*dim .. i*dim+dim)
  * in the reference's coords order: behavior[nB], discontinuousVals[nDisc], betaMild,

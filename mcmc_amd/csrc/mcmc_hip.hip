@@ -93,6 +93,8 @@ struct mcmc_hip_ctx {
     bool recSamples = false;
     /* model constants */
     DevBuf<double> dRpos, dRneg, dCapacity, dDeaths, dSigma2;
+    DevBuf<float> dRF;                  /* fast mode: float table [size + 3*MCMC_TF][16] */
+    int precision = MCMC_HIP_PRECISION_F64;
     DevBuf<int> dSeg;
     /* chain state */
     DevBuf<double> dParams, dLL, dStepsize, dHn, dHe, dD1s, dMean, dRecLL, dRecSamples;
@@ -261,6 +263,8 @@ int launch_chain_kernel(mcmc_hip_ctx* c, K kernel, bool derive, int T, Args... a
 }
 
 int run_eval_current(mcmc_hip_ctx* c) {
+    if (c->precision == MCMC_HIP_PRECISION_F32_MODEL)
+        return launch_chain_kernel(c, eval_kernel<MCMC_T, true, 1>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
     if (c->cfg.contract) return launch_chain_kernel(c, eval_kernel<MCMC_T, true>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
     return launch_chain_kernel(c, eval_kernel<MCMC_T, false>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
 }
@@ -292,6 +296,8 @@ int launch_steps(mcmc_hip_ctx* c, int nSteps, const double* dBetas, const int* d
         if (c->cfg.contract) return launch_coop(c, mh_step_coop_kernel<MCMC_T, true>, nSteps, dBetas, dFlags, slot0);
         return launch_coop(c, mh_step_coop_kernel<MCMC_T, false>, nSteps, dBetas, dFlags, slot0);
     }
+    if (c->precision == MCMC_HIP_PRECISION_F32_MODEL)
+        return launch_chain_kernel(c, mh_step_kernel<MCMC_T, true, 1>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0);
     if (c->cfg.contract)
         return launch_chain_kernel(c, mh_step_kernel<MCMC_T, true>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0);
     return launch_chain_kernel(c, mh_step_kernel<MCMC_T, false>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0);
@@ -506,6 +512,19 @@ int mcmc_hip_set_tables(mcmc_hip_ctx* c, const double* R, int32_t n_lag) try {
     HIP_TRY(hipMemcpy(c->dRneg.p, neg.data(), neg.size() * sizeof(double), hipMemcpyHostToDevice));
     c->M.Rpos = c->dRpos.p;
     c->M.Rneg = c->dRneg.p;
+    /* fast-mode table: per lag (MI HI INC MILD SER REC DEAD 0 | -SFS -RFS 1-DFS 0 | pad), every
+     * entry formed in double and rounded once; rows >= nLag stay zero */
+    std::vector<float> rf((size_t)(c->size + 3 * MCMC_TF) * MCMC_RF_STRIDE, 0.0f);
+    for (int d = 0; d < c->nLag; ++d) {
+        float* row = rf.data() + (size_t)d * MCMC_RF_STRIDE;
+        for (int k = 0; k < 7; ++k) row[k] = (float)R[(size_t)k * n_lag + d];
+        row[8] = (float)(-R[(size_t)7 * n_lag + d]);
+        row[9] = (float)(-R[(size_t)8 * n_lag + d]);
+        row[10] = (float)(1.0 - R[(size_t)9 * n_lag + d]);
+    }
+    if (int r = c->dRF.alloc(rf.size())) return r;
+    HIP_TRY(hipMemcpy(c->dRF.p, rf.data(), rf.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->M.RF = c->dRF.p;
     c->haveTables = true;
     return 0;
 } MCMC_ABI_GUARD
@@ -524,6 +543,20 @@ int mcmc_hip_set_data(mcmc_hip_ctx* c, const double* deaths, const double* sigma
     c->M.deaths = c->dDeaths.p;
     c->M.sigma2 = c->dSigma2.p;
     c->haveData = true;
+    return 0;
+} MCMC_ABI_GUARD
+
+int mcmc_hip_set_precision(mcmc_hip_ctx* c, int32_t mode) try {
+    if (int r = check_ctx(c)) return r;
+    if (mode != MCMC_HIP_PRECISION_F64 && mode != MCMC_HIP_PRECISION_F32_MODEL)
+        return fail(MCMC_HIP_EINVAL, "set_precision: unknown mode %d", mode);
+    if (mode == MCMC_HIP_PRECISION_F32_MODEL) {
+        if (!c->haveTables) return fail(MCMC_HIP_ESTATE, "set_precision: call set_tables first");
+        if (!c->cfg.contract) return fail(MCMC_HIP_EINVAL, "set_precision: the fast mode needs cfg.contract = 1");
+        if (c->coop) return fail(MCMC_HIP_EINVAL, "set_precision: the fast mode has no cooperative kernel");
+    }
+    c->precision = mode;
+    c->haveChains = false;             /* log-likelihoods of the other arithmetic are not comparable */
     return 0;
 } MCMC_ABI_GUARD
 
@@ -893,7 +926,8 @@ static int with_external(mcmc_hip_ctx* c, int64_t n, const double* params, bool 
             if (c->cfg.contract) rc = launch_chain_kernel(&tmp, derive_kernel<MCMC_T_DERIVE, true>, true, MCMC_T_DERIVE, tmp.M, tmp.S, (const double*)soa.p, res.p);
             else rc = launch_chain_kernel(&tmp, derive_kernel<MCMC_T_DERIVE, false>, true, MCMC_T_DERIVE, tmp.M, tmp.S, (const double*)soa.p, res.p);
         } else {
-            if (c->cfg.contract) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
+            if (c->precision == MCMC_HIP_PRECISION_F32_MODEL) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true, 1>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
+            else if (c->cfg.contract) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
             else rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, false>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
         }
         if (rc) break;

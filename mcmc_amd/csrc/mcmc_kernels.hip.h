@@ -77,6 +77,7 @@ struct DevModel {
     const double* deaths;         /* [nData]                                         */
     const double* sigma2;         /* [nData]  sigma[i]*sigma[i] (covid.h:491)        */
     const int* seg;               /* [simPad] piecewise-constant segment of day i, -1 = none */
+    const float* RF;              /* fast mode only (mcmc_model_f32.hip.h): [rowsF][16] floats, or null */
 };
 
 /* ------------------------------------------------------------------- pcg32 ---- */
@@ -994,6 +995,11 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
     return loglike;
 }
 
+#ifndef MCMC_TF
+#define MCMC_TF 8          /* days per register block of the fast mode */
+#endif
+#include "mcmc_model_f32.hip.h"
+
 /* t / dx / dx / dx of SmoothnessPrior::eval (mcmc.h:208).  When dx = L/n is a power of two
  * (the notebooks' L = n gives dx = 1) each division is the multiplication by the exact
  * reciprocal: the same real number rounded once, hence the same double -- without the three
@@ -1206,7 +1212,7 @@ __device__ __forceinline__ WaveBases wave_bases(const DevModel& M, const ChainSt
  * SmoothnessPrior::eval (mcmc.h:197-214), State::accept (mcmc.h:653-661) and the per-step
  * bookkeeping of MetropolisChain::run (mcmc.h:1023-1127) driven by `flags`.
  */
-template <int T, bool FUSE>
+template <int T, bool FUSE, int PREC = 0>
 __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n_steps,
                                                  const double* __restrict__ betas,
                                                  const int* __restrict__ flags, int slot0) {
@@ -1273,7 +1279,9 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
         double llpNew;
         const bool behChanged = propose(M, rnd, xc_u, xp_u, lane, stepsize, lp, llpNew);
         pc.stamp(PH_PROPOSE);
-        const double llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, pairs, pc);
+        double llm;
+        if constexpr (PREC == 1) llm = eval_model_f32<MCMC_TF>(M, lds, B, lp, lane, pairs, pc);   /* fast mode */
+        else llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, pairs, pc);
         double llp = 0.0;
         double delta = 0;                                           /* mcmc.h:604-606 */
         delta += -llModel + llm;
@@ -1463,7 +1471,7 @@ void mh_step_coop_kernel(DevModel M, ChainState S, int n_steps, const double* __
 
 /* State::eval (mcmc.h:385-393) of parameter vectors laid out [nTiles][dim][64]:
  * llOut[nTiles][2][64] */
-template <int T, bool FUSE>
+template <int T, bool FUSE, int PREC = 0>
 __global__ MCMC_KERNEL_ATTRS void eval_kernel(DevModel M, ChainState S, const double* x, double* llOut) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     const LdsView lds = stage_lds(M, lds_raw, false, T);
@@ -1476,7 +1484,9 @@ __global__ MCMC_KERNEL_ATTRS void eval_kernel(DevModel M, ChainState S, const do
     unsigned long long pairs = 0;
     PhaseClock pc;
     pc.start();
-    const double llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, pairs, pc);
+    double llm;
+    if constexpr (PREC == 1) llm = eval_model_f32<MCMC_TF>(M, lds, B, lp, lane, pairs, pc);
+    else llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, pairs, pc);
     const double llp = M.hasPrior ? eval_prior(M, B.x_u, lane) : 0.0;
     llOut[((size_t)tile * 2) * MCMC_WAVE + lane] = llm;
     llOut[((size_t)tile * 2 + 1) * MCMC_WAVE + lane] = llp;

@@ -22,7 +22,7 @@ OUT_CURVES = ["mildlyInfectious", "highlyInfectious", "incubating", "asymptomati
 SYMBOLS = [
     "mcmc_hip_last_error", "mcmc_hip_device_count", "mcmc_host_make_response_tables",
     "mcmc_host_default_disease_params", "mcmc_host_perturb_ics", "mcmc_hip_create",
-    "mcmc_hip_destroy", "mcmc_hip_set_tables", "mcmc_hip_set_data", "mcmc_hip_set_chains",
+    "mcmc_hip_destroy", "mcmc_hip_set_tables", "mcmc_hip_set_data", "mcmc_hip_set_precision", "mcmc_hip_set_chains",
     "mcmc_hip_run", "mcmc_hip_step", "mcmc_hip_n_saved", "mcmc_hip_dim", "mcmc_hip_size",
     "mcmc_hip_n_chains", "mcmc_hip_get_params", "mcmc_hip_get_loglike", "mcmc_hip_get_stepsizes",
     "mcmc_hip_get_accept_counts", "mcmc_hip_get_rng_state", "mcmc_hip_get_loglikes",
@@ -78,6 +78,7 @@ def lib():
     L.mcmc_hip_destroy.argtypes = [vp]
     L.mcmc_hip_set_tables.argtypes = [vp, dp, C.c_int32]
     L.mcmc_hip_set_data.argtypes = [vp, dp, dp]
+    L.mcmc_hip_set_precision.argtypes = [vp, C.c_int32]
     L.mcmc_hip_set_chains.argtypes = [vp, C.c_int64, dp, dp, C.POINTER(C.c_uint64), C.c_uint64]
     L.mcmc_hip_run.argtypes = [vp] + [C.c_int32] * 6
     L.mcmc_hip_step.argtypes = [vp, C.c_int32, C.c_double, C.c_int32]
@@ -181,7 +182,9 @@ class CovidSampler:
     ChainManager<MetropolisChain> + DiseaseSpread + SmoothnessPrior + Target for the covid
     model (mcmc.h:1314-1655, covid.h:284-662)."""
 
-    def __init__(self, cfg: dict, R, device=0):
+    PRECISIONS = {"f64": 0, "f32_model": 1}          # MCMC_HIP_PRECISION_*
+
+    def __init__(self, cfg: dict, R, device=0, precision="f64"):
         L = lib()
         self.cfg = cfg
         self._disc_days = np.ascontiguousarray(cfg["disc_days"], dtype=np.int32)
@@ -204,6 +207,8 @@ class CovidSampler:
         deaths = np.ascontiguousarray(cfg["deaths"], dtype=np.float64)
         sigma = np.ascontiguousarray(cfg["sigma"], dtype=np.float64)
         _check(L.mcmc_hip_set_data(self._h, _dp(deaths), _dp(sigma)))
+        if precision != "f64":
+            self.set_precision(precision)
         self.dim = L.mcmc_hip_dim(self._h)
         self.size = L.mcmc_hip_size(self._h)
         self.n_chains = 0
@@ -221,6 +226,12 @@ class CovidSampler:
             pass
 
     # --- chains -------------------------------------------------------------------------
+    def set_precision(self, precision):
+        """"f64" (the reference's arithmetic, default) or "f32_model" (fast mode: the renewal
+        convolution in packed FP32; statistical bar, see include/mcmc_hip.h).  Before set_chains."""
+        _check(lib().mcmc_hip_set_precision(self._h, self.PRECISIONS[precision]))
+        self.n_chains = 0
+
     def set_chains(self, params, stepsizes=None, chain_ids=None, first_chain_id=1):
         params = np.ascontiguousarray(params, dtype=np.float64)
         assert params.ndim == 2 and params.shape[1] == self.dim, (params.shape, self.dim)

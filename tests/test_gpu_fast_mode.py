@@ -1,0 +1,100 @@
+"""GPU tests of the FAST arithmetic mode (MCMC_HIP_PRECISION_F32_MODEL, include/mcmc_hip.h):
+the renewal convolution of DiseaseSpread::eval in packed FP32, everything else in double.
+
+This mode is not the reference's arithmetic (`using Float = double`, mcmc.h:43), so its bar is
+not bit-exactness but the one north_star states for reduced precision: log-likelihoods close
+to the FP64 kernel's (tolerances below, relative to the bit-exact path that IS held to the
+oracle) and posterior summaries of a chain ensemble within Monte-Carlo error.  What must stay
+bit-identical is everything outside the model evaluation: prior, RNG use per step, pair counts.
+"""
+import numpy as np
+import pytest
+
+from conftest import make_cfg, perturbed
+from mcmc_amd import hip as H
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(max_delay=12, n_predict=5, fix_behavior_in_advance=5, initial_delay=7.0)
+# |ll32 - ll64| <= REL * |ll64| + ABS.  FP32 rounding of the ~400-term sums behind every day's
+# deaths is ~1e-6 relative; the likelihood squares (deaths - observed), hence the absolute part.
+REL, ABS = 2e-5, 2e-2
+# 560 days of saturating epidemic with capacity corrections switching on and off: rounding
+# differences are amplified by the feedback n_{i+1} = f(buffers[i])
+REL_LONG_OVERFLOW = 1e-3
+
+
+def _pair(cfg, R10):
+    return H.CovidSampler(cfg, R10), H.CovidSampler(cfg, R10, precision="f32_model")
+
+
+@pytest.mark.parametrize("case", ["small", "overflow", "c2_200_days", "long_horizon", "long_horizon_overflow"])
+def test_fast_mode_loglike_close_to_f64(R11, R10, case):
+    if case == "small":
+        cfg = make_cfg(60, R11, contract=1, **SMALL)
+    elif case == "overflow":                       # capacity corrections on some lanes only
+        cfg = make_cfg(60, R11, contract=1, cap0=3.0, cap_incr_rate=0.5, initial_beta_mild=1.5,
+                       initial_beta_high=4.0, **SMALL)
+    elif case == "c2_200_days":                    # BASELINE configs[1] shape
+        cfg = make_cfg(200, R11, contract=1)
+    elif case == "long_horizon":                   # lags past the 500-day table: skipped chunks
+        cfg = make_cfg(520, R11, contract=1, initial_beta_mild=0.5, initial_beta_high=1.5)
+    else:                                          # ... + corrections over 500 days of feedback
+        cfg = make_cfg(520, R11, contract=1, cap0=3.0, cap_incr_rate=0.5, initial_beta_mild=1.5,
+                       initial_beta_high=4.0)
+    xs = perturbed(cfg, 130, 0.1)                  # two full tiles and a ragged one
+    if case == "overflow":
+        xs[::3, -3] *= 0.2
+        xs[::3, -2] *= 0.2
+    s64, s32 = _pair(cfg, R10)
+    a, b = s64.eval(xs), s32.eval(xs)
+    s64.close()
+    s32.close()
+    assert np.all(np.isfinite(b))
+    assert np.array_equal(a[:, 1], b[:, 1])                        # the prior is untouched
+    err = np.abs(a[:, 0] - b[:, 0])
+    rel = REL_LONG_OVERFLOW if case == "long_horizon_overflow" else REL
+    worst = int(np.argmax(err / (rel * np.abs(a[:, 0]) + ABS)))
+    assert np.all(err <= rel * np.abs(a[:, 0]) + ABS), (worst, err[worst], a[worst, 0], b[worst, 0])
+    assert np.any(a[:, 0] != b[:, 0])                              # and it really is another arithmetic
+
+
+def test_fast_mode_chains_agree_statistically(R11, R10):
+    """1024 chains, same starts / chain ids / step schedule in both modes: the ensembles'
+    acceptance and posterior summaries agree within Monte-Carlo error, per-step RNG use and
+    pair counts are identical while the chains still coincide."""
+    cfg = make_cfg(100, R11, contract=1, **SMALL)
+    xs = perturbed(cfg, 1024, 0.02)
+    out = {}
+    for name, s in zip(("f64", "f32"), _pair(cfg, R10)):
+        s.set_chains(xs)
+        s.step(1, 1.0, True)
+        first = (s.rng_state().copy(), s.pair_count())
+        s.run(400, 100, 10, 10, record_samples=True, compute_mean=True)
+        tail = np.stack([s.sample_all(k)[:, -3:] for k in range(s.n_saved)], axis=1)   # [n][saved][3]
+        out[name] = dict(first=first, acc=s.accept_counts().mean() / 400, tail=tail, mean=s.mean()[:, -3:],
+                         ll=s.loglikes())
+        s.close()
+    a, b = out["f64"], out["f32"]
+    # one step in: same draws consumed (the proposal does not depend on the model arithmetic)
+    assert np.array_equal(a["first"][0][:, 1], b["first"][0][:, 1])
+    same = np.mean(a["first"][0][:, 0] == b["first"][0][:, 0])
+    assert same > 0.99 and a["first"][1] == b["first"][1]
+    assert np.all(np.isfinite(b["ll"]))
+    assert abs(a["acc"] - b["acc"]) < 0.02, (a["acc"], b["acc"])
+    for j, nm in enumerate(["betaMild", "betaHigh", "delay"]):
+        xa, xb = a["tail"][:, -10:, j].mean(axis=1), b["tail"][:, -10:, j].mean(axis=1)
+        se = np.sqrt(xa.var(ddof=1) / len(xa) + xb.var(ddof=1) / len(xb))
+        assert abs(xa.mean() - xb.mean()) < 4 * se + 1e-12, (nm, xa.mean(), xb.mean(), se)
+        qa, qb = np.quantile(a["tail"][:, -1, j], [.05, .5, .95]), np.quantile(b["tail"][:, -1, j], [.05, .5, .95])
+        spread = qa[2] - qa[0]
+        assert np.all(np.abs(qa - qb) < 0.25 * spread), (nm, qa, qb)
+
+
+def test_fast_mode_needs_fma_contraction_and_a_known_mode(R11, R10):
+    s = H.CovidSampler(make_cfg(40, R11, contract=0, **SMALL), R10)
+    with pytest.raises(RuntimeError, match="contract"):
+        s.set_precision("f32_model")
+    with pytest.raises(RuntimeError, match="unknown mode"):
+        H._check(H.lib().mcmc_hip_set_precision(s._h, 7))
+    s.close()

@@ -19,9 +19,16 @@ def test_lag_loops_keep_their_prefetch_in_flight(tmp_path):
     r = json.loads(out.strip().splitlines()[-1])
     plain, eterm = r["plain_loop"], r["eterm_loop"]
     # two chunks of 8 lag steps per iteration: 56 (88) multiply-adds per step plus <= 7 (12) others
-    assert plain["fp64_ops"] == 896 and plain["instructions"] <= 1010
-    assert eterm["fp64_ops"] == 1408 and eterm["instructions"] <= 1600
+    assert plain["ops"] == 896 and plain["instructions"] <= 1010
+    assert eterm["ops"] == 1408 and eterm["instructions"] <= 1600
     assert plain["scratch"] == 0 and eterm["scratch"] == 0
     # the history window is refilled two chunks ahead: waits inside the loops must leave at
     # least one chunk's worth of loads (8, resp. 16 with the e-window) outstanding
     assert plain["min_vmcnt"] >= 8 and eterm["min_vmcnt"] >= 16
+    # the fast mode's loops (mcmc_model_f32.hip.h): 32 (48) packed FP32 multiply-adds per lag step
+    fplain, feterm = r["fast_plain_loop"], r["fast_eterm_loop"]
+    assert fplain["ops"] == 512 and fplain["instructions"] <= 620
+    assert feterm["ops"] == 768 and feterm["instructions"] <= 950
+    assert fplain["scratch"] == 0 and feterm["scratch"] == 0
+    assert fplain["sgpr_spill_moves"] == 0 and feterm["sgpr_spill_moves"] == 0
+    assert fplain["min_vmcnt"] >= 8 and feterm["min_vmcnt"] >= 16

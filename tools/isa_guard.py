@@ -16,26 +16,39 @@ def analyse(workdir):
            "-Wno-unused-function", "-save-temps", "-c", src, "-o", os.path.join(workdir, "x.o")]
     subprocess.run(cmd, cwd=workdir, check=True, capture_output=True)
     asm = open(os.path.join(workdir, "mcmc_hip-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
-    m = re.search(r"^_Z14mh_step_kernelILi8ELb1EE[^\n]*:.*?\.end_amdhsa_kernel", asm, re.S | re.M)
-    body = m.group(0).split("\n")
-    blocks, cur = [], None
-    for line in body:
-        if re.match(r"^\.LBB\d+_\d+:", line):
-            cur = []
-            blocks.append(cur)
-        elif cur is not None:
-            t = line.strip()
-            if t and not t.startswith((";", ".")):
-                cur.append(t)
     out = {}
-    for ins in blocks:
-        fma = sum(1 for t in ins if t.startswith(("v_fmac_f64", "v_fma_f64", "v_add_f64")))
-        name = {896: "plain_loop", 1408: "eterm_loop"}.get(fma)
-        if name is None or len(ins) < 900:
-            continue
-        waits = [int(x) for t in ins for x in re.findall(r"vmcnt\((\d+)\)", t)]
-        out[name] = {"instructions": len(ins), "fp64_ops": fma, "scratch": sum("scratch" in t for t in ins),
-                     "min_vmcnt": min(waits) if waits else None}
+    # (mangled-name prefix, instruction prefixes counted as work, {work per iteration: loop name})
+    kernels = [("_Z14mh_step_kernelILi8ELb1ELi0EE", ("v_fmac_f64", "v_fma_f64", "v_add_f64"),
+                {896: "plain_loop", 1408: "eterm_loop"}),
+               ("_Z14mh_step_kernelILi8ELb1ELi1EE", ("v_pk_fma_f32",),       # fast mode, mcmc_model_f32.hip.h
+                {512: "fast_plain_loop", 768: "fast_eterm_loop"})]
+    for sym, ops, names in kernels:
+        m = re.search(r"^" + sym + r"[^\n]*:.*?\.end_amdhsa_kernel", asm, re.S | re.M)
+        body = m.group(0).split("\n")
+        blocks, cur, label = [], None, None
+        for line in body:
+            lm = re.match(r"^(\.LBB\d+_\d+):", line)
+            if lm:
+                cur, label = [], lm.group(1)
+                blocks.append(cur)
+            elif cur is not None:
+                t = line.strip()
+                if t and not t.startswith((";", ".")):
+                    cur.append(t)
+                    if t.startswith("s_cbranch") and t.split()[-1] == label:
+                        cur = None                       # the loop ends at its backward branch
+        for ins in blocks:
+            fma = sum(1 for t in ins if t.startswith(ops))
+            name = names.get(fma)
+            if name is None or len(ins) < 500:
+                continue
+            waits = [int(x) for t in ins for x in re.findall(r"vmcnt\((\d+)\)", t)]
+            out[name] = {"instructions": len(ins), "ops": fma, "scratch": sum("scratch" in t for t in ins),
+                         "sgpr_spill_moves": sum(t.startswith(("v_readlane", "v_writelane")) for t in ins),
+                         "min_vmcnt": min(waits) if waits else None}
+        if sym.endswith("Li0EE"):
+            m0 = m
+    m = m0
     vg = re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(0))
     out["vgprs"] = int(vg.group(1)) if vg else None
     return out
