@@ -93,7 +93,7 @@ struct mcmc_hip_ctx {
     bool recSamples = false;
     /* model constants */
     DevBuf<double> dRpos, dRneg, dCapacity, dDeaths, dSigma2;
-    DevBuf<float> dRF;                  /* fast mode: float table [size + 3*MCMC_TF][16] */
+    DevBuf<float> dRF;                  /* fast mode: float tables [size + 3*MCMC_TF][8] and [..][4] */
     int precision = MCMC_HIP_PRECISION_F64;
     DevBuf<int> dSeg;
     /* chain state */
@@ -512,19 +512,23 @@ int mcmc_hip_set_tables(mcmc_hip_ctx* c, const double* R, int32_t n_lag) try {
     HIP_TRY(hipMemcpy(c->dRneg.p, neg.data(), neg.size() * sizeof(double), hipMemcpyHostToDevice));
     c->M.Rpos = c->dRpos.p;
     c->M.Rneg = c->dRneg.p;
-    /* fast-mode table: per lag (MI HI INC MILD SER REC DEAD 0 | -SFS -RFS 1-DFS 0 | pad), every
-     * entry formed in double and rounded once; rows >= nLag stay zero */
-    std::vector<float> rf((size_t)(c->size + 3 * MCMC_TF) * MCMC_RF_STRIDE, 0.0f);
+    /* fast-mode tables: per lag (MI HI INC MILD SER REC DEAD 0) and (-SFS -RFS 1-DFS 0), every
+     * entry formed in double and rounded once; rows >= nLag stay zero.  One buffer: the
+     * positive table first, the correction table behind it. */
+    const size_t rowsF = (size_t)c->size + 3 * MCMC_TF;
+    std::vector<float> rf(rowsF * 12, 0.0f);
     for (int d = 0; d < c->nLag; ++d) {
-        float* row = rf.data() + (size_t)d * MCMC_RF_STRIDE;
-        for (int k = 0; k < 7; ++k) row[k] = (float)R[(size_t)k * n_lag + d];
-        row[8] = (float)(-R[(size_t)7 * n_lag + d]);
-        row[9] = (float)(-R[(size_t)8 * n_lag + d]);
-        row[10] = (float)(1.0 - R[(size_t)9 * n_lag + d]);
+        float* rowp = rf.data() + (size_t)d * 8;
+        float* rown = rf.data() + rowsF * 8 + (size_t)d * 4;
+        for (int k = 0; k < 7; ++k) rowp[k] = (float)R[(size_t)k * n_lag + d];
+        rown[0] = (float)(-R[(size_t)7 * n_lag + d]);
+        rown[1] = (float)(-R[(size_t)8 * n_lag + d]);
+        rown[2] = (float)(1.0 - R[(size_t)9 * n_lag + d]);
     }
     if (int r = c->dRF.alloc(rf.size())) return r;
     HIP_TRY(hipMemcpy(c->dRF.p, rf.data(), rf.size() * sizeof(float), hipMemcpyHostToDevice));
     c->M.RF = c->dRF.p;
+    c->M.RFn = c->dRF.p + rowsF * 8;
     c->haveTables = true;
     return 0;
 } MCMC_ABI_GUARD

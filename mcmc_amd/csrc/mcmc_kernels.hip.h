@@ -77,7 +77,8 @@ struct DevModel {
     const double* deaths;         /* [nData]                                         */
     const double* sigma2;         /* [nData]  sigma[i]*sigma[i] (covid.h:491)        */
     const int* seg;               /* [simPad] piecewise-constant segment of day i, -1 = none */
-    const float* RF;              /* fast mode only (mcmc_model_f32.hip.h): [rowsF][16] floats, or null */
+    const float* RF;              /* fast mode only (mcmc_model_f32.hip.h): [rowsF][8] floats, or null */
+    const float* RFn;             /* fast mode only: [rowsF][4] floats                                  */
 };
 
 /* ------------------------------------------------------------------- pcg32 ---- */
@@ -995,9 +996,10 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
     return loglike;
 }
 
-#ifndef MCMC_TF
-#define MCMC_TF 8          /* days per register block of the fast mode */
-#endif
+/* days per register block of the fast mode.  Fixed: a T=16 build (fewer history loads per
+ * multiply-add) needs 256+256 registers, 399 SGPR spills and scratch for its unrolled day loop
+ * and ended in a memory fault on the GPU when tried; only T=8 is validated on hardware. */
+#define MCMC_TF 8
 #include "mcmc_model_f32.hip.h"
 
 /* t / dx / dx / dx of SmoothnessPrior::eval (mcmc.h:208).  When dx = L/n is a power of two

@@ -16,7 +16,7 @@
  *  - the seven accumulator families of a day sit in four float2 registers
  *    (MI,HI) (INC,MILD) (SER,REC) (DEAD,-) and one lag step of one day is four
  *    v_pk_fma_f32 -- the history value broadcast to both halves by op_sel, the table row
- *    read from SGPRs (one s_load_dwordx8 per lag step);
+ *    read from SGPRs (one s_load_dwordx16 per two lag steps);
  *  - the per-lane histories are float (half the re-read traffic), kept in the same buffers;
  *  - the capacity correction of a source day is two packed multiply-adds per pair, with the
  *    row (-SFS, -RFS, 1-DFS, 0) prepared by the host (in double, rounded once): dead += e and
@@ -30,16 +30,17 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef float float8_t __attribute__((ext_vector_type(8)));
 
-#define MCMC_RF_STRIDE 16      /* floats per row of the float table: 8 positive curves, 4 correction terms, 4 pad */
+/* float tables of the fast mode: RFpos [rows][8] = MI HI INC MILD SER REC DEAD 0, RFneg [rows][4] =
+ * -SFS -RFS 1-DFS 0; rows >= nLagRows are zero */
 enum { P_INF = 0, P_IM, P_SR, P_D, P_N };     /* (MI,HI) (INC,MILD) (SER,REC) (DEAD,0) */
 
 typedef const __attribute__((address_space(4))) float8_t* const_rowf8_ptr;
 typedef const __attribute__((address_space(4))) float4_t* const_rowf4_ptr;
-__device__ __forceinline__ float8_t smem_rowf8(const float* RF, int L) {
-    return *(const_rowf8_ptr)(RF + (long long)L * MCMC_RF_STRIDE);
+__device__ __forceinline__ float8_t smem_rowf8(const float* RFpos, int L) {
+    return *(const_rowf8_ptr)(RFpos + (long long)L * 8);
 }
-__device__ __forceinline__ float4_t smem_rowf4(const float* RF, int L) {
-    return *(const_rowf4_ptr)(RF + (long long)L * MCMC_RF_STRIDE + 8);
+__device__ __forceinline__ float4_t smem_rowf4(const float* RFneg, int L) {
+    return *(const_rowf4_ptr)(RFneg + (long long)L * 4);
 }
 __device__ __forceinline__ float ld_rowf(const float* base_u, int row, unsigned lane) {
     const char* b = (const char*)(base_u + (size_t)row * MCMC_WAVE);
@@ -63,57 +64,95 @@ __device__ __forceinline__ void pair_neg(float2_t (&acc)[P_N][T], int t, float e
     acc[P_D][t] = fma2(ek, rn[2], rn[3], acc[P_D][t]);
 }
 
-/* one chunk of T lags on the T days of the block; windows and row pipeline as in lag_chunk */
+/* Table rows of the lag loops.  Scalar loads return out of order, so every wait for one is a
+ * wait for ALL outstanding ones (lgkmcnt(0)): however many steps ahead a row is requested, the
+ * lead that counts is the time since the LAST request.  A packed lag step is only ~170 cycles
+ * of arithmetic -- less than the scalar cache's latency -- so the rows travel in GROUPS of two
+ * lag steps: one s_load_dwordx16 (two 8-float rows, consecutive in memory because lags descend)
+ * is requested at the start of a group for the NEXT group and first read two steps later.  The
+ * group in use is carried across chunks (`cur`); the rows the last chunk of a block requests
+ * below lag T are in bounds and unused. */
+typedef float float16u_t __attribute__((ext_vector_type(16))) __attribute__((aligned(32)));
+typedef float float8u_t __attribute__((ext_vector_type(8))) __attribute__((aligned(16)));
+typedef const __attribute__((address_space(4))) float16u_t* const_rowf16_ptr;
+typedef const __attribute__((address_space(4))) float8u_t* const_rowf8u_ptr;
+/* rows L and L+1 of the 8-float table: [0..7] = row L, [8..15] = row L+1 */
+__device__ __forceinline__ float16u_t smem_rows2(const float* RFpos, int L) {
+    return *(const_rowf16_ptr)(RFpos + (long long)L * 8);
+}
+/* rows L and L+1 of the 4-float correction table */
+__device__ __forceinline__ float8u_t smem_rows2n(const float* RFneg, int L) {
+    return *(const_rowf8u_ptr)(RFneg + (long long)L * 4);
+}
+__device__ __forceinline__ float8_t hi8(const float16u_t& v) { return float8_t{v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]}; }
+__device__ __forceinline__ float8_t lo8(const float16u_t& v) { return float8_t{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}; }
+__device__ __forceinline__ float4_t hi4(const float8u_t& v) { return float4_t{v[4], v[5], v[6], v[7]}; }
+__device__ __forceinline__ float4_t lo4(const float8u_t& v) { return float4_t{v[0], v[1], v[2], v[3]}; }
+
+/* one chunk of T lags (Lc, Lc-1, ..., Lc-T+1) on the T days of the block; history windows as in
+ * lag_chunk.  cur = rows (Lc-1, Lc) on entry, rows (Lc-T-1, Lc-T) on exit. */
 template <int T>
-__device__ __forceinline__ void lag_chunk_f(float2_t (&acc)[P_N][T], float (&W)[T], const float (&N)[T], float8_t& r,
-                                            const float* RF, int Lc, const float* hn_next_u, unsigned lane) {
-    const float* rowBase = RF + (long long)(Lc - T) * MCMC_RF_STRIDE;    /* rows Lc-T .. Lc-1 */
-    float8_t r1 = smem_rowf8(rowBase, T - 1);
+__device__ __forceinline__ void lag_chunk_f(float2_t (&acc)[P_N][T], float (&W)[T], const float (&N)[T], float16u_t& cur,
+                                            const float* RFpos, int Lc, const float* hn_next_u, unsigned lane) {
+    static_assert(T % 2 == 0, "rows travel in pairs");
+    const float* rowBase = RFpos + (long long)(Lc - T - 1) * 8;            /* one address per chunk */
 #pragma unroll
-    for (int u = 0; u < T; ++u) {
-        const float8_t rnext = r1;
-        r1 = smem_rowf8(rowBase, T - 2 - u);                              /* two steps ahead */
+    for (int g = 0; g < T / 2; ++g) {
+        const float16u_t nxt = smem_rows2(rowBase, T - 2 - 2 * g);         /* rows Lc-2g-3, Lc-2g-2 */
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int q = t + u;
-            const float nk = (q < T) ? W[q < T ? q : 0] : N[q < T ? 0 : q - T];
-            pair_pos<T>(acc, t, nk, r);
+        for (int h = 0; h < 2; ++h) {
+            const int u = 2 * g + h;
+            const float8_t r = h == 0 ? hi8(cur) : lo8(cur);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int q = t + u;
+                const float nk = (q < T) ? W[q < T ? q : 0] : N[q < T ? 0 : q - T];
+                pair_pos<T>(acc, t, nk, r);
+            }
+            W[u] = ld_rowf(hn_next_u, u, lane);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        W[u] = ld_rowf(hn_next_u, u, lane);
-        r = rnext;
-        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
     }
 }
 
 template <int T>
 __device__ __forceinline__ void lag_chunk_fe(float2_t (&acc)[P_N][T], float (&W)[T], const float (&N)[T], float (&EW)[T],
-                                             const float (&EN)[T], float8_t& r, float4_t& rn, const float* RF, int Lc,
-                                             const float* hn_next_u, const float* he_next_u, unsigned lane) {
-    const float* rowBase = RF + (long long)(Lc - T) * MCMC_RF_STRIDE;
+                                             const float (&EN)[T], float16u_t& cur, float8u_t& curn, const float* RFpos,
+                                             const float* RFneg, int Lc, const float* hn_next_u, const float* he_next_u,
+                                             unsigned lane) {
+    const float* rowBase = RFpos + (long long)(Lc - T - 1) * 8;
+    const float* rowBaseN = RFneg + (long long)(Lc - T - 1) * 4;
 #pragma unroll
-    for (int u = 0; u < T; ++u) {
-        const float8_t rnext = smem_rowf8(rowBase, T - 1 - u);
-        const float4_t rnnext = smem_rowf4(rowBase, T - 1 - u);
+    for (int g = 0; g < T / 2; ++g) {
+        const float16u_t nxt = smem_rows2(rowBase, T - 2 - 2 * g);
+        const float8u_t nxtn = smem_rows2n(rowBaseN, T - 2 - 2 * g);
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int q = t + u;
-            const float nk = (q < T) ? W[q < T ? q : 0] : N[q < T ? 0 : q - T];
-            const float ek = (q < T) ? EW[q < T ? q : 0] : EN[q < T ? 0 : q - T];
-            pair_pos<T>(acc, t, nk, r);
-            pair_neg<T>(acc, t, ek, rn);
+        for (int h = 0; h < 2; ++h) {
+            const int u = 2 * g + h;
+            const float8_t r = h == 0 ? hi8(cur) : lo8(cur);
+            const float4_t rn = h == 0 ? hi4(curn) : lo4(curn);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int q = t + u;
+                const float nk = (q < T) ? W[q < T ? q : 0] : N[q < T ? 0 : q - T];
+                const float ek = (q < T) ? EW[q < T ? q : 0] : EN[q < T ? 0 : q - T];
+                pair_pos<T>(acc, t, nk, r);
+                pair_neg<T>(acc, t, ek, rn);
+            }
+            W[u] = ld_rowf(hn_next_u, u, lane);
+            EW[u] = ld_rowf(he_next_u, u, lane);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        W[u] = ld_rowf(hn_next_u, u, lane);
-        EW[u] = ld_rowf(he_next_u, u, lane);
-        r = rnext;
-        rn = rnnext;
-        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+        curn = nxtn;
     }
 }
 
 /* the lags T-1 .. 1 whose source days lie before the block */
 template <int T, bool WITH_E>
-__device__ __forceinline__ void lag_tail_f(float2_t (&acc)[P_N][T], const float (&W)[T], const float* RF,
-                                           const float* he_k0_u, unsigned lane) {
+__device__ __forceinline__ void lag_tail_f(float2_t (&acc)[P_N][T], const float (&W)[T], const float* RFpos,
+                                           const float* RFneg, const float* he_k0_u, unsigned lane) {
     float ek[WITH_E ? T - 1 : 1];
     if constexpr (WITH_E) {
 #pragma unroll
@@ -122,9 +161,9 @@ __device__ __forceinline__ void lag_tail_f(float2_t (&acc)[P_N][T], const float 
 #pragma unroll
     for (int v = 1; v < T; ++v) {
         const int L = T - v;
-        const float8_t r = smem_rowf8(RF, L);
+        const float8_t r = smem_rowf8(RFpos, L);
         float4_t rn;
-        if constexpr (WITH_E) rn = smem_rowf4(RF, L);
+        if constexpr (WITH_E) rn = smem_rowf4(RFneg, L);
 #pragma unroll
         for (int t = 0; t < L; ++t) {
             pair_pos<T>(acc, t, W[t + v - 1], r);
@@ -136,7 +175,7 @@ __device__ __forceinline__ void lag_tail_f(float2_t (&acc)[P_N][T], const float 
 /*
  * The fast-mode model evaluation for the chain of this lane; returns loglike (double).
  * B.hn_u / B.he_u are used as float rows (the buffers are sized for doubles), B.d1s_u stays
- * double.  `RF` = M.RF, the float table [rows][16].
+ * double.  M.RF / M.RFn are the float tables.
  */
 template <int T>
 __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsView& lds, const WaveBases& B,
@@ -144,7 +183,8 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
                                                  PhaseClock& pc) {
     const int md = M.md;
     const int horizon = M.simDays;
-    const float* RF = M.RF;
+    const float* RFpos = M.RF;
+    const float* RFneg = M.RFn;
     float* hn_u = (float*)B.hn_u;
     float* he_u = (float*)B.he_u;
     const double* xdisc_u = B.x_u + M.nB * MCMC_WAVE;
@@ -210,7 +250,7 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
                     WB[q] = hbase[(c0 * T + q + T) * MCMC_WAVE + lane];
                 }
             }
-            float8_t r = smem_rowf8(RF, Lc);
+            float16u_t cur = smem_rows2(RFpos, Lc - 1);
             const float* hnx = hbase + (c0 + 2) * T * MCMC_WAVE;
             int cLo = b, cHi = b - 1;
             if (anyE) {
@@ -231,13 +271,13 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
                 if (seg != 1) {
 #pragma unroll 1
                     for (; nch >= 2; nch -= 2) {
-                        lag_chunk_f<T>(acc, WA, WB, r, RF, Lc, hnx, laneL);
-                        lag_chunk_f<T>(acc, WB, WA, r, RF, Lc - T, hnx + T * MCMC_WAVE, laneL);
+                        lag_chunk_f<T>(acc, WA, WB, cur, RFpos, Lc, hnx, laneL);
+                        lag_chunk_f<T>(acc, WB, WA, cur, RFpos, Lc - T, hnx + T * MCMC_WAVE, laneL);
                         hnx += 2 * T * MCMC_WAVE;
                         Lc -= 2 * T;
                     }
                     if (nch > 0) {
-                        lag_chunk_f<T>(acc, WA, WB, r, RF, Lc, hnx, laneL);
+                        lag_chunk_f<T>(acc, WA, WB, cur, RFpos, Lc, hnx, laneL);
 #pragma unroll
                         for (int q = 0; q < T; ++q) { const float tmp = WA[q]; WA[q] = WB[q]; WB[q] = tmp; }
                         hnx += T * MCMC_WAVE;
@@ -251,18 +291,18 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
                         EB[q] = ek0[(q + T) * MCMC_WAVE + laneL];
                     }
                     const float* ekx = ek0 + 2 * T * MCMC_WAVE;
-                    float4_t rn = smem_rowf4(RF, Lc);
+                    float8u_t curn = smem_rows2n(RFneg, Lc - 1);
                     if (nch >= 2) __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0) ahead of the loop header */
 #pragma unroll 1
                     for (; nch >= 2; nch -= 2) {
-                        lag_chunk_fe<T>(acc, WA, WB, EA, EB, r, rn, RF, Lc, hnx, ekx, laneL);
-                        lag_chunk_fe<T>(acc, WB, WA, EB, EA, r, rn, RF, Lc - T, hnx + T * MCMC_WAVE, ekx + T * MCMC_WAVE, laneL);
+                        lag_chunk_fe<T>(acc, WA, WB, EA, EB, cur, curn, RFpos, RFneg, Lc, hnx, ekx, laneL);
+                        lag_chunk_fe<T>(acc, WB, WA, EB, EA, cur, curn, RFpos, RFneg, Lc - T, hnx + T * MCMC_WAVE, ekx + T * MCMC_WAVE, laneL);
                         hnx += 2 * T * MCMC_WAVE;
                         ekx += 2 * T * MCMC_WAVE;
                         Lc -= 2 * T;
                     }
                     if (nch > 0) {
-                        lag_chunk_fe<T>(acc, WA, WB, EA, EB, r, rn, RF, Lc, hnx, ekx, laneL);
+                        lag_chunk_fe<T>(acc, WA, WB, EA, EB, cur, curn, RFpos, RFneg, Lc, hnx, ekx, laneL);
 #pragma unroll
                         for (int q = 0; q < T; ++q) { const float tmp = WA[q]; WA[q] = WB[q]; WB[q] = tmp; }
                         hnx += T * MCMC_WAVE;
@@ -284,9 +324,9 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
             }
             pc.stamp(PH_CHUNKS);
             if (anyE && j0 - T + 1 <= keHi && j0 - 1 >= keLo)
-                lag_tail_f<T, true>(acc, WA, RF, ebase + b * T * MCMC_WAVE, lane);
+                lag_tail_f<T, true>(acc, WA, RFpos, RFneg, ebase + b * T * MCMC_WAVE, lane);
             else
-                lag_tail_f<T, false>(acc, WA, RF, nullptr, lane);
+                lag_tail_f<T, false>(acc, WA, RFpos, RFneg, nullptr, lane);
             pc.stamp(PH_TAIL);
             if (b > 0) {
 #pragma unroll
@@ -301,7 +341,7 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
             for (int t = 0; t < T; ++t) {
                 const int i = j0 + t;
 #pragma unroll
-                for (int tt = t; tt < T; ++tt) pair_pos<T>(acc, tt, ncur, smem_rowf8(RF, tt - t));   /* covid.h:403-410 */
+                for (int tt = t; tt < T; ++tt) pair_pos<T>(acc, tt, ncur, smem_rowf8(RFpos, tt - t));   /* covid.h:403-410 */
                 /* hospital capacity (covid.h:413-429), decided in double */
                 const double overCapacity = (double)acc[P_SR][t].x * M.probICU - capv[t];
                 const double extraDeaths = M.probLethal * overCapacity;
@@ -312,7 +352,7 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
                     keLo = min(keLo, i);
                     keHi = max(keHi, i);
 #pragma unroll
-                    for (int tt = t; tt < T; ++tt) pair_neg<T>(acc, tt, e, smem_rowf4(RF, tt - t));
+                    for (int tt = t; tt < T; ++tt) pair_neg<T>(acc, tt, e, smem_rowf4(RFneg, tt - t));
                 }
                 /* tomorrow's new infections (covid.h:446-462), in double */
                 const double pcf = pcfv[t];
