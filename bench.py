@@ -145,6 +145,9 @@ def main():
                     help="adjust-phase iterations (20 MH steps each, mcmc.h:1083-1119) run untimed before the warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-leg", action="store_true", help="skip the FP32 fast-mode leg (N=1 only)")
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32_model"],
+                    help="arithmetic of the MAIN leg; f32_model (fast mode) is for profiling that kernel only: "
+                         "the line then says dtype f32+f64 and is not the headline metric")
     ap.add_argument("--ess-chains", type=int, default=4096, help="chains of the ESS leg (0: skip it)")
     ap.add_argument("--ess-steps", type=int, default=2000)
     # BASELINE.json configs[3] (extension): ladders of K temperatures, whole ladders per GPU
@@ -174,7 +177,9 @@ def main():
 
     n_chains = args.chains_per_gpu
     first_id = 1 + rank * n_chains                       # contiguous chain-id ranges
-    cfg, R, xs, s = build_workload(device, n_chains, first_id, args.contract)
+    cfg, R, xs, s = build_workload(device, n_chains, first_id, args.contract, precision=args.precision)
+    fast_main = args.precision != "f64"
+    peak = PEAK_FP32_VECTOR_TFLOPS if fast_main else PEAK_FP64_VECTOR_TFLOPS
 
     def sync():
         torch.cuda.synchronize()
@@ -228,7 +233,7 @@ def main():
         achieved = flops / ksec / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not fast_main:
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
@@ -237,7 +242,9 @@ def main():
             "metric": "MH steps/sec (whole node) on covid model, 64k chains",
             "value": value, "unit": "MH steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 packed (renewal convolution) + f64 -- FAST MODE, not the headline metric" if fast_main else "f64",
+            "data": "synthetic",
             "config": {"workload": f"covid.h model, {n_chains} independent chains per GPU, 365-day synthetic "
                                    "series, chain-sharded (BASELINE.json configs[2])",
                        "chains_per_gpu": n_chains, "n_data": N_DATA, "dim": cfg["dim"],
@@ -246,8 +253,8 @@ def main():
                        **({"ladder": {"temperatures": args.ladder, "t_max": args.ladder_tmax,
                                       "swap_every": args.swap_every}} if args.ladder else {}),
                        "parallelism": f"chain-shard x{world}"},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP64_VECTOR_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VECTOR_TFLOPS,
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "kernel": "mh_step_kernel",
                          "kernel_ms_per_launch": 1e3 * ksec / max(launches, 1), "launches": launches,
                          "steps_per_launch": args.steps / max(launches, 1),
@@ -268,7 +275,7 @@ def main():
             cb = cpu_baseline(cfg, R, cpu_start[0], cpu_start[1], args.contract)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = value / cb["value"]
-        if world == 1 and not args.no_fast_leg and not args.ladder and args.contract:
+        if world == 1 and not args.no_fast_leg and not args.ladder and args.contract and not fast_main:
             out["fp32_fast_mode"] = fast_mode_leg(cfg, R, device, xs, first_id, args)
             out["fp32_fast_mode"]["speedup_over_f64"] = out["fp32_fast_mode"]["value"] / value
         if world == 1 and args.ess_chains > 0 and not args.ladder:
