@@ -189,6 +189,7 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
     float* he_u = (float*)B.he_u;
     const double* xdisc_u = B.x_u + M.nB * MCMC_WAVE;
     constexpr int HOFF = 2 * T;
+    const double invPop = 1.0 / M.pop;
 
     double loglike = 0;
     int start = (int)((double)md - lp.delay);                       /* covid.h:331 */
@@ -362,7 +363,9 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
                 const double mild = (double)acc[P_IM][t].y;
                 const double nSus = M.pop - (double)acc[P_IM][t].x - mild - mild - (double)acc[P_SR][t].x -
                                     (double)acc[P_SR][t].y - (double)acc[P_D][t].x;
-                double nnext = totalBehavior * nSus / M.pop *
+                /* * (1/pop) instead of / pop: one rounding apart, and the division sequence is the
+                 * longest link of the day-to-day dependency chain */
+                double nnext = totalBehavior * nSus * invPop *
                                (lp.betaMild * (double)acc[P_INF][t].x + lp.betaHigh * (double)acc[P_INF][t].y);
                 if (i < s) nnext = (i + 1 == s) ? 1.0 : 0.0;
                 const float nnf = (float)nnext;
