@@ -239,7 +239,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "MH steps/sec (whole node) on covid model, 64k chains",
+            "metric": "MH steps/sec (whole node) on covid model, 64k chains; ESS/sec vs CPU TBB",   # BASELINE.json's string; ESS/s is in "ess"
             "value": value, "unit": "MH steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
