@@ -111,6 +111,8 @@ struct mcmc_hip_ctx {
     unsigned long long swapRounds[2] = {0, 0};
     /* cooperative pair of waves per tile (MCMC_HIP_COOP=1) */
     bool coop = false;
+    /* the two passes of an evaluation in two waves of a SIMD (MCMC_HIP_SPLIT=1) */
+    bool split = false;
     DevBuf<int> dCoopErr;
     /* scratch */
     DevBuf<double> dBetas;
@@ -292,6 +294,12 @@ int launch_coop(mcmc_hip_ctx* c, K kernel, int nSteps, const double* dBetas, con
 }
 
 int launch_steps(mcmc_hip_ctx* c, int nSteps, const double* dBetas, const int* dFlags, int slot0) {
+    if (c->split && c->precision == MCMC_HIP_PRECISION_F64) {
+        if (c->dHn.n < (size_t)2 * c->histRows * c->nP)
+            return fail(MCMC_HIP_ESTATE, "split kernel: the history buffers hold one set only");
+        if (c->cfg.contract) return launch_coop(c, mh_step_split_kernel<MCMC_T, true>, nSteps, dBetas, dFlags, slot0);
+        return launch_coop(c, mh_step_split_kernel<MCMC_T, false>, nSteps, dBetas, dFlags, slot0);
+    }
     if (c->coop) {
         if (c->cfg.contract) return launch_coop(c, mh_step_coop_kernel<MCMC_T, true>, nSteps, dBetas, dFlags, slot0);
         return launch_coop(c, mh_step_coop_kernel<MCMC_T, false>, nSteps, dBetas, dFlags, slot0);
@@ -432,6 +440,8 @@ static int init_ctx(mcmc_hip_ctx* c, const mcmc_covid_config* cfg, int device) {
     c->device = device;
     HIP_TRY(hipDeviceGetAttribute(&c->nCU, hipDeviceAttributeMultiprocessorCount, device));
     { const char* e = std::getenv("MCMC_HIP_COOP"); c->coop = e && std::atoi(e) != 0; }
+    { const char* e = std::getenv("MCMC_HIP_SPLIT"); c->split = e && std::atoi(e) != 0; }
+    if (c->split && c->coop) return fail(MCMC_HIP_EINVAL, "create: MCMC_HIP_SPLIT and MCMC_HIP_COOP exclude each other");
     c->size = cfg->max_delay + cfg->n_predict + cfg->n_data;          /* covid.h:297 */
     c->nB = cfg->n_data - cfg->fix_behavior_in_advance;               /* covid.h:299 */
     c->dim = c->nB + cfg->n_disc + 3;
@@ -557,7 +567,7 @@ int mcmc_hip_set_precision(mcmc_hip_ctx* c, int32_t mode) try {
     if (mode == MCMC_HIP_PRECISION_F32_MODEL) {
         if (!c->haveTables) return fail(MCMC_HIP_ESTATE, "set_precision: call set_tables first");
         if (!c->cfg.contract) return fail(MCMC_HIP_EINVAL, "set_precision: the fast mode needs cfg.contract = 1");
-        if (c->coop) return fail(MCMC_HIP_EINVAL, "set_precision: the fast mode has no cooperative kernel");
+        if (c->coop || c->split) return fail(MCMC_HIP_EINVAL, "set_precision: the fast mode has no cooperative / split kernel");
     }
     c->precision = mode;
     c->haveChains = false;             /* log-likelihoods of the other arithmetic are not comparable */
@@ -566,8 +576,9 @@ int mcmc_hip_set_precision(mcmc_hip_ctx* c, int32_t mode) try {
 
 static int alloc_work(mcmc_hip_ctx* c, long long nP) {
     /* history + LL scratch for nP lanes; contents are fully rewritten by every evaluation */
-    if (int r = c->dHn.alloc((size_t)c->histRows * nP)) return r;
-    if (int r = c->dHe.alloc((size_t)c->histRows * nP)) return r;
+    const size_t sets = c->split ? 2 : 1;          /* SPLIT: a history set per pass (mh_step_split_kernel) */
+    if (int r = c->dHn.alloc(sets * (size_t)c->histRows * nP)) return r;
+    if (int r = c->dHe.alloc(sets * (size_t)c->histRows * nP)) return r;
     if (int r = c->dD1s.alloc((size_t)2 * c->cfg.n_data * nP)) return r;
     HIP_TRY(hipMemsetAsync(c->dHn.p, 0, c->dHn.n * sizeof(double), c->stream));
     HIP_TRY(hipMemsetAsync(c->dHe.p, 0, c->dHe.n * sizeof(double), c->stream));
