@@ -26,8 +26,10 @@
  * needs none of its own).  Phase A walks the lags L = j-k from large to small (= k
  * ascending) in chunks of T lags: per lag ONE history value per lane is loaded
  * (coalesced 8 B/lane, requested two chunks = 16 lags ahead) and feeds 7*T multiply-adds
- * whose second operand R_c[L] is wave-uniform: one row of the response table, read from
- * the workgroup's LDS image as a broadcast one lag ahead of use.  Source days that carry a
+ * whose second operand R_c[L] is wave-uniform: one row of the response table, fetched by one
+ * scalar load two lags ahead of use and read from SGPRs (MCMC_SMEM_TABLE; the workgroup's LDS
+ * image of the table serves the sequential part, the e-term rows and the strict / derive
+ * paths).  Source days that carry a
  * hospital-capacity correction form a wave-uniform day range; only the chunks reading
  * that range take the variant with the extra e-terms.  Phase B then runs the T days of
  * the block in order (the feedback n_{i+1} = f(buffers[i]) is inherently sequential,
