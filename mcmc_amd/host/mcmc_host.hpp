@@ -192,6 +192,10 @@ public:
     int popSize;
     double cap0, capIncrRate;
     std::shared_ptr<const std::vector<double>> responseTable;      /* [10][500] */
+    /* Extension, no counterpart in the reference: run the renewal convolution of eval in packed
+     * FP32 on the device (MCMC_HIP_PRECISION_F32_MODEL, include/mcmc_hip.h).  Off = `Float` is
+     * double everywhere, as in the reference (mcmc.h:43). */
+    bool fastMode = false;
 
     static constexpr uint64_t kTrajectories = 10000000;             /* covid.h:207 */
 
@@ -333,6 +337,7 @@ public:
         try {
             hip_check(mcmc_hip_set_tables(ctx, ds.responseTable->data(), MCMC_HIP_TRAJ_NDAYS), "mcmc_hip_set_tables");
             hip_check(mcmc_hip_set_data(ctx, ds.data.deathsPerDay.data(), ds.data.deathsSigma.data()), "mcmc_hip_set_data");
+            if (ds.fastMode) hip_check(mcmc_hip_set_precision(ctx, MCMC_HIP_PRECISION_F32_MODEL), "mcmc_hip_set_precision");
         } catch (...) { mcmc_hip_destroy(ctx); ctx = nullptr; throw; }
         dim = mcmc_hip_dim(ctx);
         size = mcmc_hip_size(ctx);

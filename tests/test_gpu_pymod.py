@@ -92,6 +92,24 @@ def test_chain_run_equals_oracle_chain(cooling):
     assert np.array_equal(chain.get_samples("betaHigh"), samples[2:, -2:-1])
 
 
+def test_fast_mode_through_the_module():
+    """DiseaseSpread.fastMode (extension): the module's chains run the packed-FP32 convolution;
+    log-likelihoods stay within the fast mode's tolerance of the double ones (tests/test_gpu_fast_mode.py)."""
+    data, p, ds, state, target, cfg, m, tgt = _setup(T=1.0)
+    ll64 = state.loglike()
+    ds.fastMode = True
+    state.init()
+    ll32 = state.loglike()
+    assert ll32 != ll64 and abs(ll32 - ll64) <= 2e-5 * abs(ll64) + 2e-2
+    chain = mcmc.Chain(target, 3)
+    chain.run(40, 0, 2, 5)
+    lls = np.asarray(chain.get_loglikes())
+    oc = O.OracleChain(m, 3, CC.initial_params(cfg))
+    ref, _, _ = oc.run(tgt, 40, 0, 2, 5, record=False)
+    assert len(lls) == len(ref) and np.all(np.isfinite(lls))
+    assert abs(lls[0] - ref[0]) <= 2e-5 * abs(ref[0]) + 2e-2          # the start point, before the chains diverge
+
+
 def test_text_dump_of_run_and_reevaluate(tmp_path, monkeypatch):
     """samples<id>.txt: "chainweight w" from run (mcmc.h:1018), "chainweight = w" from
     reevaluate (mcmc.h:1167); then per saved point "weight w loglike l" and one
