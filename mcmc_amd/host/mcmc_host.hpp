@@ -382,6 +382,13 @@ public:
     /* MetropolisChain::run for n chains with ids firstId.. */
     virtual void run(BatchResults& R, size_t n, const Float* x, const Float* ss, uint64_t firstId, int nSamples,
                      int nBurnin, int nAdjust, int thinning) = 0;
+    /* Tempering ladders (extension, no counterpart in the reference): chains [L*K, (L+1)*K) form ladder L on the
+     * temperatures `temps`; nRounds x (stepsPerRound MH steps, one exchange round).  rungs[i] = the rung chain i
+     * ends on; swapAcc/swapProp [K-1] per neighbouring pair. */
+    virtual void run_tempered(BatchResults&, size_t, const Float*, const Float*, uint64_t, const std::vector<Float>&,
+                              uint64_t, int, int, std::vector<int32_t>&, std::vector<int64_t>&, std::vector<int64_t>&) {
+        throw std::logic_error("run_tempered: only the covid state has a tempering ladder");
+    }
 };
 
 class CovidBackend : public Backend {
@@ -418,6 +425,27 @@ public:
         R.diagnostics.assign(4 + 2 * d, 0);
         hip_check(mcmc_hip_diagnostics(eng.ctx, R.diagnostics.data()), "mcmc_hip_diagnostics");
         R.n = n; R.dim = d; R.nOut = d; R.nSaved = nSaved;
+    }
+    void run_tempered(BatchResults& R, size_t n, const Float* x, const Float* ss, uint64_t firstId,
+                      const std::vector<Float>& temps, uint64_t swapSeed, int nRounds, int stepsPerRound,
+                      std::vector<int32_t>& rungs, std::vector<int64_t>& swapAcc, std::vector<int64_t>& swapProp) override {
+        const size_t d = dim(), K = temps.size();
+        hip_check(mcmc_hip_set_chains(eng.ctx, (int64_t)n, x, ss, nullptr, firstId), "mcmc_hip_set_chains");
+        hip_check(mcmc_hip_set_ladder(eng.ctx, (int32_t)K, temps.data(), swapSeed, 0), "mcmc_hip_set_ladder");
+        hip_check(mcmc_hip_run_tempered(eng.ctx, nRounds, stepsPerRound), "mcmc_hip_run_tempered");
+        R = BatchResults{};
+        R.params.assign(n * d, 0); R.mean.assign(n * d, 0); R.fll.assign(n * 2, 0); R.fss.assign(n, 0); R.acc.assign(n, 0);
+        hip_check(mcmc_hip_get_params(eng.ctx, R.params.data()), "mcmc_hip_get_params");
+        R.mean = R.params;                                   /* no running mean in a tempered run */
+        hip_check(mcmc_hip_get_loglike(eng.ctx, R.fll.data()), "mcmc_hip_get_loglike");
+        hip_check(mcmc_hip_get_stepsizes(eng.ctx, R.fss.data()), "mcmc_hip_get_stepsizes");
+        hip_check(mcmc_hip_get_accept_counts(eng.ctx, R.acc.data()), "mcmc_hip_get_accept_counts");
+        rungs.assign(n, 0); swapAcc.assign(K - 1, 0); swapProp.assign(K - 1, 0);
+        hip_check(mcmc_hip_get_rungs(eng.ctx, rungs.data()), "mcmc_hip_get_rungs");
+        hip_check(mcmc_hip_get_swap_counts(eng.ctx, swapAcc.data(), swapProp.data()), "mcmc_hip_get_swap_counts");
+        R.diagnostics.assign(4 + 2 * d, 0);
+        hip_check(mcmc_hip_diagnostics(eng.ctx, R.diagnostics.data()), "mcmc_hip_diagnostics");
+        R.n = n; R.dim = d; R.nOut = d; R.nSaved = 0;
     }
     Engine eng;
 };
@@ -937,6 +965,41 @@ public:
         if (nRun > 0) stepsizes = {R.fss[0]};
         while (stepsizes.size() < target->state->state.size()) stepsizes.push_back(1);
     }
+    /* Extension (BASELINE configs[3]; the reference has no replica exchange): the manager's chains as
+     * ladders of temps.size() temperatures -- chains [L*K, (L+1)*K) are ladder L, rung r starts on
+     * TempTarget(temps[r]) -- advanced by nRounds x (stepsPerRound MH steps + one exchange round, even and
+     * odd neighbour pairs alternating).  Exchanges swap temperatures, not states; tempered_rungs() tells
+     * which rung every chain ended on (rung 0 of temps[0] = 1 holds the posterior's samples).  Step sizes as
+     * in run_all.  One batched device run, like run_all. */
+    void run_tempered(const std::vector<Float>& temps, size_t nRounds, size_t stepsPerRound, uint64_t swapSeed) {
+        chains.clear();
+        nRun = 0;
+        std::string why;
+        if (!target->state || !target->state->supported(&why)) { std::cout << "ChainManager: " << why << ".\n"; return; }
+        const size_t n = chainICs.size(), K = temps.size();
+        if (K < 2 || n == 0 || n % K != 0) {
+            std::cout << "ChainManager::run_tempered: need at least 2 temperatures and a chain count that is a multiple of their number.\n";
+            return;
+        }
+        State& st = *target->state;
+        std::unique_ptr<Backend> be = st.backend(target->spec());
+        const size_t dim = be->dim();
+        std::vector<Float> flat(n * dim);
+        for (size_t i = 0; i < n; ++i) {
+            if (chainICs[i].first[0].size() != dim) { std::cout << "ChainManager: initial condition " << i << " has the wrong dimension.\n"; return; }
+            std::copy(chainICs[i].first[0].begin(), chainICs[i].first[0].end(), flat.begin() + i * dim);
+        }
+        std::vector<Float> ss(n, stepsizes.empty() ? 1.0 : stepsizes[0]);
+        be->run_tempered(R, n, flat.data(), ss.data(), 1, temps, swapSeed, (int)nRounds, (int)stepsPerRound, rungs,
+                         swapAccepted, swapProposed);
+        last_diagnostics = R.diagnostics;
+        nRun = n;
+        std::cout << "Tempered chain runs completed." << std::endl << std::endl;
+    }
+    const std::vector<int32_t>& tempered_rungs() const { return rungs; }
+    const std::vector<int64_t>& swaps_accepted() const { return swapAccepted; }
+    const std::vector<int64_t>& swaps_proposed() const { return swapProposed; }
+
     /* mcmc.h:1555-1565 (the reference's bare `throw;` terminates; an exception is kinder) */
     MetropolisChain& get_chain(size_t i) {
         if (nRun == 0) {
@@ -1059,6 +1122,8 @@ protected:
     BatchResults R;
     size_t nRun = 0;
     std::map<size_t, MetropolisChain> chains;
+    std::vector<int32_t> rungs;
+    std::vector<int64_t> swapAccepted, swapProposed;
 
     MetropolisChain& materialize(size_t i) {
         auto it = chains.find(i);

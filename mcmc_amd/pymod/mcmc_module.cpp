@@ -149,6 +149,19 @@ PYBIND11_MODULE(mcmc, m) {
         .def("get_chain", &ChainManager::get_chain, py::return_value_policy::reference_internal)
         /* not in the reference: bulk access for many chains and caller-chosen starts */
         .def("set_initial_conditions", &ChainManager::set_initial_conditions)
+        /* tempering ladders (extension): temps, rounds, MH steps per round, seed of the exchange draws */
+        .def("run_tempered", &ChainManager::run_tempered, py::call_guard<py::gil_scoped_release>(),
+             py::arg("temps"), py::arg("n_rounds"), py::arg("steps_per_round"), py::arg("swap_seed") = 1)
+        .def("tempered_rungs", [](const ChainManager& c) { return std::vector<int>(c.tempered_rungs().begin(), c.tempered_rungs().end()); })
+        .def("swap_counts", [](const ChainManager& c) {
+            return std::make_pair(std::vector<long long>(c.swaps_accepted().begin(), c.swaps_accepted().end()),
+                                  std::vector<long long>(c.swaps_proposed().begin(), c.swaps_proposed().end()));
+        })
+        .def("all_final_params", [](const ChainManager& c) {
+            py::array_t<Float> a({c.n_chains(), (size_t)c.n_dim()});
+            std::copy(c.all_final_params().begin(), c.all_final_params().end(), a.mutable_data());
+            return a;
+        })
         .def("n_chains", &ChainManager::n_chains)
         .def("chain_weight", &ChainManager::chain_weight)
         .def("all_loglikes", [](const ChainManager& c) {

@@ -110,6 +110,36 @@ def test_fast_mode_through_the_module():
     assert abs(lls[0] - ref[0]) <= 2e-5 * abs(ref[0]) + 2e-2          # the start point, before the chains diverge
 
 
+def test_tempering_ladders_through_the_module():
+    """ChainManager.run_tempered (extension, BASELINE configs[3]) is the C ABI's ladder: the same chains
+    through the ctypes view -- which tests/test_gpu_tempering.py holds to the oracle -- end bit-identically."""
+    from mcmc_amd import hip as H
+    data, p, ds, state, target, cfg, m, tgt = _setup(T=1.0)
+    x0 = CC.initial_params(cfg)
+    rng = np.random.default_rng(5)
+    xs = x0 * (1 + 0.02 * (rng.random((8, x0.size)) - 0.5))
+    temps = [1.0, 2.0, 4.0, 8.0]
+    cm = mcmc.ChainManager(target, 2)
+    cm.set_initial_conditions([list(x) for x in xs])
+    cm.run_tempered(temps, 5, 4, 9)                      # 2 ladders x 4 rungs, 5 rounds of 4 steps
+    R10 = np.ascontiguousarray(ds.response_table())
+    s = H.CovidSampler(cfg, R10)
+    s.set_chains(xs)
+    s.set_ladder(temps, swap_seed=9, first_ladder=0)
+    s.run_tempered(5, 4)
+    assert np.array_equal(cm.all_final_params(), s.params())
+    assert list(cm.tempered_rungs()) == list(s.rungs())
+    acc, prop = cm.swap_counts()
+    a2, p2 = s.swap_counts()
+    assert list(acc) == list(a2) and list(prop) == list(p2) and sum(prop) > 0
+    c = cm.get_chain(5)
+    assert c.weight == 1 and ds is not None
+    s.close()
+    cm.run_tempered([1.0, 2.0, 3.0], 1, 1, 1)            # 8 chains are not a multiple of 3: refused, prints
+    with pytest.raises(IndexError):
+        cm.get_chain(0)
+
+
 def test_text_dump_of_run_and_reevaluate(tmp_path, monkeypatch):
     """samples<id>.txt: "chainweight w" from run (mcmc.h:1018), "chainweight = w" from
     reevaluate (mcmc.h:1167); then per saved point "weight w loglike l" and one
