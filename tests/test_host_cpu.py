@@ -163,3 +163,15 @@ def test_ess_geyer_on_ar1_chains():
     assert np.all(np.abs(ess / (n * (1 - phi) / (1 + phi)) - 1) < 0.25)
     assert np.all(np.abs(SH.ess_geyer(e) / n - 1) < 0.1)
     assert np.array_equal(SH.ess_geyer(np.ones((2, 50))), np.zeros(2))       # a chain that never moved
+
+
+def test_bench_fails_loudly_without_a_gpu():
+    """bench.py has no CPU fallback: without a device it stops before building any workload."""
+    import subprocess
+    import sys
+    if H.lib().mcmc_hip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no GPU visible" in (r.stderr + r.stdout)
+    assert "{" not in r.stdout                       # and prints no result line
