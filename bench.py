@@ -85,10 +85,11 @@ def cpu_baseline(cfg, R10, xs, stepsizes, contract, seconds=20.0):
 
 
 def ess_leg(cfg, R, device, contract, xs, stepsizes, first_id, n_steps, thinning):
-    """ESS per MH step of delay / betaMild / betaHigh from a recorded run of a
-    subset of the chains, continued from the adapted state.  Chains are bit-identical on the
-    CPU path, so ESS/s on either side = ESS per step x that side's steps/s."""
-    from mcmc_amd.sharding import ess_geyer
+    """ESS per MH step of delay / betaMild / betaHigh and R-hat from a recorded run of a
+    subset of this rank's chains, continued from the adapted state.  Returns the ADDITIVE pieces
+    (one vector, summed over ranks by one all-reduce) -- see ess_finish.  Chains are bit-identical on
+    the CPU path, so ESS/s on either side = ESS per step x that side's steps/s."""
+    from mcmc_amd.sharding import ess_geyer, moment_sums
     n = xs.shape[0]
     s = H.CovidSampler(cfg, R, device)
     s.set_chains(xs, stepsizes=stepsizes, first_chain_id=first_id)
@@ -96,15 +97,21 @@ def ess_leg(cfg, R, device, contract, xs, stepsizes, first_id, n_steps, thinning
     n_saved = s.n_saved
     dim = cfg["dim"]
     tail = np.stack([s.sample_all(k)[:, dim - 3:] for k in range(n_saved)], axis=1)    # [n][n_saved][3]
-    acc = s.accept_counts().mean() / n_steps
+    acc = float(s.accept_counts().sum())
     s.close()
+    ess = [float(ess_geyer(tail[:, :, j]).sum()) for j in range(3)]                  # Geyer, per chain, summed
+    return np.concatenate([[float(n), acc], ess, moment_sums(tail)]), n_saved
+
+
+def ess_finish(tot, n_saved, n_steps, thinning, ranks):
+    from mcmc_amd.sharding import rhat_ess
     names = ["betaMild", "betaHigh", "delay"]
-    per_step = {nm: float(ess_geyer(tail[:, :, j]).sum() / (n * n_steps)) for j, nm in enumerate(names)}
-    from mcmc_amd.sharding import moment_sums, rhat_ess
-    rhat, _ = rhat_ess(moment_sums(tail), 3, n_saved)                # Gelman-Rubin over the recorded stretch
-    return {"ess_per_step": per_step, "acceptance": float(acc), "rhat": dict(zip(names, map(float, rhat))),
-            "sample": f"{n} chains x {n_steps} steps after the adaptation, every {thinning}th point, Geyer initial "
-                      "positive sequence per chain, summed over chains"}
+    n = tot[0]
+    rhat, _ = rhat_ess(tot[5:], 3, n_saved)                                          # Gelman-Rubin over all chains
+    return {"ess_per_step": {nm: float(tot[2 + j] / (n * n_steps)) for j, nm in enumerate(names)},
+            "acceptance": float(tot[1] / (n * n_steps)), "rhat": dict(zip(names, map(float, rhat))),
+            "sample": f"{int(n)} chains ({ranks} rank(s)) x {n_steps} steps after the adaptation, every {thinning}th point, "
+                      "Geyer initial positive sequence per chain, summed over chains; R-hat over all of them"}
 
 
 def fast_mode_leg(cfg, R, device, xs, first_id, args):
@@ -194,7 +201,7 @@ def main():
         s.set_ladder(temps, swap_seed=1, first_ladder=rank * (n_chains // args.ladder))
     s.step(args.warmup, 1.0, True)
     n_keep = max(256, min(args.ess_chains, n_chains))
-    cpu_start = (s.params()[:n_keep].copy(), s.stepsizes()[:n_keep].copy()) if rank == 0 else None
+    cpu_start = (s.params()[:n_keep].copy(), s.stepsizes()[:n_keep].copy())
     s.pair_count(reset=True)
     t_before = s.last_timing()
     diag_before = s.diagnostics()                        # additive sums of this shard (untimed)
@@ -220,6 +227,14 @@ def main():
     diag_after = s.diagnostics()
     local = np.concatenate([[diag_after[0] - diag_before[0], float(n_chains)], diag_after[2:]])
     tot = allreduce_sum(local)
+
+    # ESS / R-hat leg on every rank (its first --ess-chains chains), pieces summed by one more all-reduce
+    ess_tot = None
+    if args.ess_chains > 0 and not args.ladder and not (args.precision != "f64"):
+        ne = min(args.ess_chains, n_chains)
+        pieces, ess_saved = ess_leg(cfg, R, device, args.contract, cpu_start[0][:ne], cpu_start[1][:ne], first_id,
+                                    args.ess_steps, 5)
+        ess_tot = allreduce_sum(pieces)
 
     if rank == 0:
         total_steps = world * n_chains * args.steps
@@ -278,11 +293,10 @@ def main():
         if world == 1 and not args.no_fast_leg and not args.ladder and args.contract and not fast_main:
             out["fp32_fast_mode"] = fast_mode_leg(cfg, R, device, xs, first_id, args)
             out["fp32_fast_mode"]["speedup_over_f64"] = out["fp32_fast_mode"]["value"] / value
-        if world == 1 and args.ess_chains > 0 and not args.ladder:
-            ne = min(args.ess_chains, n_chains)
-            e = ess_leg(cfg, R, device, args.contract, cpu_start[0][:ne], cpu_start[1][:ne], first_id, args.ess_steps, 5)
+        if ess_tot is not None:
+            e = ess_finish(ess_tot, ess_saved, args.ess_steps, 5, world)
             worst = min(e["ess_per_step"].values())
-            e["gpu_ess_per_s"] = worst * value            # slowest-mixing of the three coordinates
+            e["gpu_ess_per_s"] = worst * value            # slowest-mixing of the three coordinates, whole job
             if "cpu_baseline" in out:
                 e["cpu_ess_per_s"] = worst * out["cpu_baseline"]["value"]
             out["ess"] = e
