@@ -28,10 +28,12 @@ def _pair(cfg, R10):
     return H.CovidSampler(cfg, R10), H.CovidSampler(cfg, R10, precision="f32_model")
 
 
-@pytest.mark.parametrize("case", ["small", "overflow", "c2_200_days", "long_horizon", "long_horizon_overflow"])
+@pytest.mark.parametrize("case", ["small", "no_prediction_days", "overflow", "c2_200_days", "long_horizon", "long_horizon_overflow"])
 def test_fast_mode_loglike_close_to_f64(R11, R10, case):
     if case == "small":
         cfg = make_cfg(60, R11, contract=1, **SMALL)
+    elif case == "no_prediction_days":             # the last block overhangs the horizon by 6 days
+        cfg = make_cfg(45, R11, contract=1, **dict(SMALL, n_predict=0))
     elif case == "overflow":                       # capacity corrections on some lanes only
         cfg = make_cfg(60, R11, contract=1, cap0=3.0, cap_incr_rate=0.5, initial_beta_mild=1.5,
                        initial_beta_high=4.0, **SMALL)

@@ -102,6 +102,35 @@ def test_eval_delay_edge_cases(R11, R10):
     s.close()
 
 
+@pytest.mark.parametrize("n_data", [45, 48])
+def test_no_prediction_days(R11, R10, n_data):
+    """nPredictDays = 0 (covid.h:294 takes a size_t): the simulated horizon is the whole series, so the
+    last 8-day block overhangs the arrays' logical end by up to 6 days (n_data = 45: 57 days = 7 blocks
+    + 1) -- eval, derive and MH steps against the oracle, delays spread over both bounds."""
+    kw = dict(SMALL, n_predict=0)
+    cfg = make_cfg(n_data, R11, **kw)
+    assert cfg["size"] == 12 + n_data
+    m = O.Model(cfg, R11)
+    xs = perturbed(cfg, 70, 0.05)
+    delays = [5.0, 12.0, 7.0, 6.0, 11.999999, 5.000001, 8.5, 9.25]
+    for i in range(70):
+        xs[i, -1] = delays[i % len(delays)]
+    s = H.CovidSampler(cfg, R10)
+    ll = s.eval(xs)
+    ref = np.array([[m.eval(x), m.prior(x)] for x in xs])
+    assert np.array_equal(ll, ref)
+    cur = s.derive(xs[:4])
+    refc = np.array([m.eval(x, curves=True)[1] for x in xs[:4]])
+    assert np.array_equal(cur, refc)
+    tgt = O.make_target("temp", 1.0)
+    s.set_chains(xs)
+    s.step(6, 1.0, True)
+    st = _state(s)
+    for c in (0, 63, 69):
+        _assert_chain_equal(_oracle_after_steps(m, tgt, c + 1, xs[c], 6), st, c)
+    s.close()
+
+
 def test_long_horizon_beyond_the_trajectory_table(R11, R10):
     """size = 40 + 60 + 520 = 620 days > traj.nDays = 500: lags past the table contribute
     nothing (the `d < nDays` cut of project(), covid.h:378), whole chunks of them are skipped
