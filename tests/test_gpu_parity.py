@@ -307,6 +307,26 @@ def test_many_breakpoints(R11, R10):
     s.close()
 
 
+def test_single_breakpoint_and_behavior_over_all_data_days(R11, R10):
+    """One breakpoint (days before it have no piecewise factor, covid.h:432-444) and
+    fixBehaviorInAdvance = 0 (the behaviour function spans every data day, covid.h:299)."""
+    kw = dict(SMALL, fix_behavior_in_advance=0)
+    cfg = make_cfg(50, R11, disc_days=(9,), disc_vals=(.7,), disc_fixed=[0], **kw)
+    assert cfg["n_disc"] == 1 and cfg["nB"] == 50
+    m = O.Model(cfg, R11)
+    xs = perturbed(cfg, 64, 0.05)
+    s = H.CovidSampler(cfg, R10)
+    ll = s.eval(xs)
+    assert np.array_equal(ll, np.array([[m.eval(x), m.prior(x)] for x in xs]))
+    s.set_chains(xs)
+    s.step(25, 1.0, True)
+    st = _state(s)
+    tgt = O.make_target("temp", 1.0)
+    for c in (0, 17, 63):
+        _assert_chain_equal(_oracle_after_steps(m, tgt, c + 1, xs[c], 25), st, c)
+    s.close()
+
+
 # ------------------------------------------------------------- MetropolisChain::run ----
 @pytest.mark.parametrize("target", [("temp", 1.0, 0.0, 1.0), ("cooling", 1.0, 2.5, 8.0), ("plain", 1.0, 0.0, 1.0)])
 def test_run_matches_oracle_run(R11, R10, target):
