@@ -61,6 +61,31 @@ def test_fast_mode_loglike_close_to_f64(R11, R10, case):
     assert np.any(a[:, 0] != b[:, 0])                              # and it really is another arithmetic
 
 
+def test_fast_mode_is_deterministic_and_independent_of_the_batch(R11, R10):
+    """A chain's fast-mode result depends on its own inputs only: the wave-uniform shortcuts (common
+    first day, chunks with capacity corrections) add exact zeros for the lanes they do not concern.
+    Same bits for any order / composition of the batch, run after run, steps included."""
+    cfg = make_cfg(60, R11, contract=1, cap0=3.0, cap_incr_rate=0.5, initial_beta_mild=1.5, initial_beta_high=4.0, **SMALL)
+    xs = perturbed(cfg, 130, 0.1)
+    xs[::3, -3] *= 0.2                               # lanes with and without corrections in one wave
+    xs[::3, -2] *= 0.2
+    xs[::5, -1] = 11.5                               # and very different first days
+    perm = np.random.default_rng(3).permutation(130)
+    s = H.CovidSampler(cfg, R10, precision="f32_model")
+    a = s.eval(xs)
+    assert np.array_equal(a, s.eval(xs))
+    assert np.array_equal(a[perm], s.eval(xs[perm]))
+    assert np.array_equal(a[:7], s.eval(xs[:7]))
+    ids = np.arange(1, 131, dtype=np.uint64)
+    s.set_chains(xs, chain_ids=ids)
+    s.step(12, 1.0, True)
+    p1, r1 = s.params(), s.rng_state()
+    s.set_chains(xs[perm], chain_ids=ids[perm])
+    s.step(12, 1.0, True)
+    assert np.array_equal(p1[perm], s.params()) and np.array_equal(r1[perm], s.rng_state())
+    s.close()
+
+
 def test_fast_mode_chains_agree_statistically(R11, R10):
     """1024 chains, same starts / chain ids / step schedule in both modes: the ensembles'
     acceptance and posterior summaries agree within Monte-Carlo error, per-step RNG use and
