@@ -86,6 +86,37 @@ def test_fast_mode_is_deterministic_and_independent_of_the_batch(R11, R10):
     s.close()
 
 
+def test_fast_mode_full_size_properties(R11, R10):
+    """BASELINE configs[2] shape (365 days, dim 358) at 16384 chains in the fast mode: a scattered
+    subset run alone ends on the same bits, a repeat run is bit-identical, the log-likelihoods of the
+    start points agree with the FP64 kernel's, and every chain consumed its own RNG stream."""
+    from mcmc_amd import covid_config as CC
+    cfg = make_cfg(365, R11, contract=1)
+    n = 16384
+    xs = H.perturb_ics(CC.initial_params(cfg), n, 0.01)
+    big = H.CovidSampler(cfg, R10, precision="f32_model")
+    big.set_chains(xs, first_chain_id=1)
+    ll0 = big.loglike().copy()
+    big.step(3, 1.0, True)
+    P, LL, RNG = big.params(), big.loglike(), big.rng_state()
+    assert np.all(np.isfinite(LL))
+    idx = np.array([0, 1, 63, 64, 4097, 9999, n - 1])
+    sub = H.CovidSampler(cfg, R10, precision="f32_model")
+    sub.set_chains(xs[idx], chain_ids=idx + 1)
+    sub.step(3, 1.0, True)
+    assert np.array_equal(sub.params(), P[idx]) and np.array_equal(sub.loglike(), LL[idx])
+    assert np.array_equal(sub.rng_state(), RNG[idx])
+    big.set_chains(xs, first_chain_id=1)
+    big.step(3, 1.0, True)
+    assert np.array_equal(P, big.params()) and np.array_equal(LL, big.loglike()) and np.array_equal(RNG, big.rng_state())
+    assert np.all(RNG[:, 1] == (2 * (np.arange(n, dtype=np.uint64) + 1) + 1))
+    f64 = H.CovidSampler(cfg, R10)
+    ref = f64.eval(xs[:256])
+    assert np.all(np.abs(ref[:, 0] - ll0[:256, 0]) <= REL * np.abs(ref[:, 0]) + ABS)
+    for s in (big, sub, f64):
+        s.close()
+
+
 def test_fast_mode_chains_agree_statistically(R11, R10):
     """1024 chains, same starts / chain ids / step schedule in both modes: the ensembles'
     acceptance and posterior summaries agree within Monte-Carlo error, per-step RNG use and
