@@ -1,0 +1,110 @@
+// Prototype of the fast mode's phase A on the FP32 matrix cores: for one
+// tile of 64 chains and one 8-day block starting at day j0,
+//     acc[chain][t][c] = sum over source days k < K of hist[k][chain] * table[j0 + t - k][c]
+// with v_mfma_f32_32x32x2_f32: M = 32 chains, N = 32 = 4 days x 8 curves, K = 2 source days.
+// (1) checks the operand / result lane maps against a host sum, (2) times the loop with one wave
+// per SIMD, every wave streaming a history slab of its own.  Compiler builtins only.
+// Build: hipcc --offload-arch=gfx950 -O3 -o mfma_conv_proto mfma_conv_proto.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+typedef float float16_t __attribute__((ext_vector_type(16)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+constexpr int PAD = 32;          // rows of zeros behind every history slab: the prefetch ring reads ahead
+constexpr int RING = 8;          // source-day pairs in flight
+
+// hist: [tiles][K + PAD][64], table: [rowsT][8], out: [tiles][64 chains][64 = 8 days x 8 curves]
+__global__ __launch_bounds__(64) void conv_mfma(const float* __restrict__ hist, const float* __restrict__ table,
+                                                float* __restrict__ out, int K, int rowsT, int j0, int reps) {
+    extern __shared__ float lds[];
+    for (int i = threadIdx.x; i < rowsT * 8; i += 64) lds[i] = table[i];
+    __syncthreads();
+    const int l = threadIdx.x, half = l >> 5, n = l & 31;
+    const float* h = hist + (size_t)blockIdx.x * (K + PAD) * 64;
+    float16_t acc[2][2];
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    for (int rep = 0; rep < reps; ++rep) {
+        float ra[RING][2];
+#pragma unroll
+        for (int u = 0; u < RING; ++u) {
+            ra[u][0] = h[(2 * u + half) * 64 + n];
+            ra[u][1] = h[(2 * u + half) * 64 + n + 32];
+        }
+        for (int k0 = 0; k0 < K; k0 += 2 * RING) {
+#pragma unroll
+            for (int u = 0; u < RING; ++u) {
+                const int k = k0 + 2 * u;                       // this pair: source days k, k+1
+                int row = j0 - k - half;                         // table row of (t = 0, this lane's source day)
+                row = row < 0 ? 0 : row;                         // k >= K only (prefetch tail): history is zero there
+                const float b0 = lds[row * 8 + n];               // days j0 .. j0+3
+                const float b1 = lds[(row + 4) * 8 + n];         // days j0+4 .. j0+7
+                const float a0 = ra[u][0], a1 = ra[u][1];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                const int kn = k + 2 * RING;                     // refill the slot: <= K - 2 + 16 < K + PAD
+                ra[u][0] = h[(kn + half) * 64 + n];
+                ra[u][1] = h[(kn + half) * 64 + n + 32];
+            }
+        }
+    }
+    float* o = out + (size_t)blockIdx.x * 64 * 64;
+    for (int mt = 0; mt < 2; ++mt)
+        for (int nt = 0; nt < 2; ++nt)
+            for (int v = 0; v < 16; ++v) {
+                const int chain = 32 * mt + 8 * (v / 4) + 4 * half + (v % 4);
+                o[chain * 64 + 32 * nt + n] = acc[mt][nt][v];
+            }
+}
+
+int main() {
+    const int K = 384, j0 = 400, rowsT = 416, tilesCheck = 2, tiles = 1024;
+    if (K % (2 * RING) != 0 || j0 - (K - 1) < 0 || j0 + 7 + 4 >= rowsT) { printf("bad shape\n"); return 1; }
+    std::vector<float> hist((size_t)tiles * (K + PAD) * 64, 0.0f), table((size_t)rowsT * 8, 0.0f);
+    srand(7);
+    for (int t = 0; t < tiles; ++t)
+        for (int k = 0; k < K; ++k)
+            for (int c = 0; c < 64; ++c) hist[((size_t)t * (K + PAD) + k) * 64 + c] = (float)(rand() % 2000) / 1000.0f;
+    for (int r = 0; r < rowsT; ++r)
+        for (int c = 0; c < 7; ++c) table[r * 8 + c] = (float)(rand() % 1000) / 1000.0f;
+    float *dh, *dt, *dout;
+    CK(hipMalloc(&dh, hist.size() * 4)); CK(hipMalloc(&dt, table.size() * 4)); CK(hipMalloc(&dout, (size_t)tiles * 4096 * 4));
+    CK(hipMemcpy(dh, hist.data(), hist.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dt, table.data(), table.size() * 4, hipMemcpyHostToDevice));
+    const size_t shmem = (size_t)rowsT * 8 * 4;
+    hipLaunchKernelGGL(conv_mfma, dim3(tilesCheck), dim3(64), shmem, 0, dh, dt, dout, K, rowsT, j0, 1);
+    CK(hipGetLastError()); CK(hipDeviceSynchronize());
+    std::vector<float> out((size_t)tilesCheck * 4096);
+    CK(hipMemcpy(out.data(), dout, out.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0;
+    for (int t = 0; t < tilesCheck; ++t)
+        for (int ch = 0; ch < 64; ++ch)
+            for (int d = 0; d < 8; ++d)
+                for (int c = 0; c < 8; ++c) {
+                    double s = 0;
+                    for (int k = 0; k < K; ++k) s += (double)hist[((size_t)t * (K + PAD) + k) * 64 + ch] * table[(j0 + d - k) * 8 + c];
+                    const double got = out[(size_t)t * 4096 + ch * 64 + d * 8 + c];
+                    const double err = fabs(got - s) / (fabs(s) + 1e-3);
+                    if (err > worst) worst = err;
+                }
+    printf("lane maps: worst relative error against the host sum %.3g (%s)\n", worst, worst < 1e-4 ? "ok" : "WRONG");
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int reps = 20;
+    float ms = 0;
+    for (int r = 0; r < 2; ++r) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(conv_mfma, dim3(tiles), dim3(64), shmem, 0, dh, dt, dout, K, rowsT, j0, reps);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    const double pairs = (double)tiles * reps * K * 64 * 8;               // (chain, day, source day) triples
+    printf("1024 waves, %d source days x %d reps: %.3f ms  %.1f TFLOP/s issued (8 columns), %.1f useful (7 curves); "
+           "%.0f ns per source day per wave\n", K, reps, ms, pairs * 8 * 2 / ms / 1e9, pairs * 7 * 2 / ms / 1e9,
+           ms * 1e6 / ((double)reps * K));
+    return 0;
+}
