@@ -12,8 +12,8 @@
 #include <vector>
 typedef float float16_t __attribute__((ext_vector_type(16)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
-constexpr int PAD = 32;          // rows of zeros behind every history slab: the prefetch ring reads ahead
-constexpr int RING = 8;          // source-day pairs in flight
+constexpr int PAD = 64;          // rows of zeros behind every history slab: the prefetch ring reads ahead
+constexpr int RING = 16;         // source-day pairs in flight (8: 86 ns per source day, latency-bound)
 
 // hist: [tiles][K + PAD][64], table: [rowsT][8], out: [tiles][64 chains][64 = 8 days x 8 curves]
 __global__ __launch_bounds__(64) void conv_mfma(const float* __restrict__ hist, const float* __restrict__ table,
@@ -34,22 +34,31 @@ __global__ __launch_bounds__(64) void conv_mfma(const float* __restrict__ hist, 
             ra[u][0] = h[(2 * u + half) * 64 + n];
             ra[u][1] = h[(2 * u + half) * 64 + n + 32];
         }
+        /* B operands one pair ahead of their MFMAs (LDS latency off the critical path) */
+        int row = j0 - half;
+        float b0 = lds[row * 8 + n], b1 = lds[(row + 4) * 8 + n];
         for (int k0 = 0; k0 < K; k0 += 2 * RING) {
 #pragma unroll
             for (int u = 0; u < RING; ++u) {
                 const int k = k0 + 2 * u;                       // this pair: source days k, k+1
-                int row = j0 - k - half;                         // table row of (t = 0, this lane's source day)
-                row = row < 0 ? 0 : row;                         // k >= K only (prefetch tail): history is zero there
-                const float b0 = lds[row * 8 + n];               // days j0 .. j0+3
-                const float b1 = lds[(row + 4) * 8 + n];         // days j0+4 .. j0+7
+                int rown = j0 - (k + 2) - half;                  // table row of the NEXT pair
+                rown = rown < 0 ? 0 : rown;                      // beyond K only: history is zero there
+                const float nb0 = lds[rown * 8 + n];             // days j0 .. j0+3
+                const float nb1 = lds[(rown + 4) * 8 + n];       // days j0+4 .. j0+7
+                /* the MFMAs block the wave's issue for 64 cycles each: the reads for the next pair have
+                 * to be in the queue BEFORE them, or their latency is exposed after them */
+                __builtin_amdgcn_sched_barrier(0);
                 const float a0 = ra[u][0], a1 = ra[u][1];
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-                const int kn = k + 2 * RING;                     // refill the slot: <= K - 2 + 16 < K + PAD
+                const int kn = k + 2 * RING;                     // refill the slot: <= K - 2 + 2*RING + 1 < K + PAD
                 ra[u][0] = h[(kn + half) * 64 + n];
                 ra[u][1] = h[(kn + half) * 64 + n + 32];
+                b0 = nb0;
+                b1 = nb1;
+                __builtin_amdgcn_sched_barrier(0);               // keep every pair's loads in its step
             }
         }
     }
