@@ -34,17 +34,17 @@ __global__ __launch_bounds__(64) void conv_mfma(const float* __restrict__ hist, 
             ra[u][0] = h[(2 * u + half) * 64 + n];
             ra[u][1] = h[(2 * u + half) * 64 + n + 32];
         }
-        /* B operands one pair ahead of their MFMAs (LDS latency off the critical path) */
-        int row = j0 - half;
-        float b0 = lds[row * 8 + n], b1 = lds[(row + 4) * 8 + n];
+        /* B operands one pair ahead of their MFMAs (LDS latency off the critical path); one running LDS
+         * index and one running history pointer, no clamps (the shape check guarantees j0 >= K + 2) */
+        int li = (j0 - half) * 8 + n;
+        float b0 = lds[li], b1 = lds[li + 32];
+        const float* hp = h + (2 * RING + half) * 64 + n;       // refill source of pair 0
         for (int k0 = 0; k0 < K; k0 += 2 * RING) {
 #pragma unroll
             for (int u = 0; u < RING; ++u) {
-                const int k = k0 + 2 * u;                       // this pair: source days k, k+1
-                int rown = j0 - (k + 2) - half;                  // table row of the NEXT pair
-                rown = rown < 0 ? 0 : rown;                      // beyond K only: history is zero there
-                const float nb0 = lds[rown * 8 + n];             // days j0 .. j0+3
-                const float nb1 = lds[(rown + 4) * 8 + n];       // days j0+4 .. j0+7
+                li -= 16;                                        // table row of the NEXT pair: two days on
+                const float nb0 = lds[li];                       // days j0 .. j0+3
+                const float nb1 = lds[li + 32];                  // days j0+4 .. j0+7
                 /* the MFMAs block the wave's issue for 64 cycles each: the reads for the next pair have
                  * to be in the queue BEFORE them, or their latency is exposed after them */
                 __builtin_amdgcn_sched_barrier(0);
@@ -53,13 +53,13 @@ __global__ __launch_bounds__(64) void conv_mfma(const float* __restrict__ hist, 
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-                const int kn = k + 2 * RING;                     // refill the slot: <= K - 2 + 2*RING + 1 < K + PAD
-                ra[u][0] = h[(kn + half) * 64 + n];
-                ra[u][1] = h[(kn + half) * 64 + n + 32];
+                ra[u][0] = hp[u * 128];                          // pair k + 2*RING: rows <= K + 2*RING - 1 < K + PAD
+                ra[u][1] = hp[u * 128 + 32];
                 b0 = nb0;
                 b1 = nb1;
                 __builtin_amdgcn_sched_barrier(0);               // keep every pair's loads in its step
             }
+            hp += 2 * RING * 64;
         }
     }
     float* o = out + (size_t)blockIdx.x * 64 * 64;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void conv_mfma(const float* __restrict__ hist, 
 
 int main() {
     const int K = 384, j0 = 400, rowsT = 416, tilesCheck = 2, tiles = 1024;
-    if (K % (2 * RING) != 0 || j0 - (K - 1) < 0 || j0 + 7 + 4 >= rowsT) { printf("bad shape\n"); return 1; }
+    if (K % (2 * RING) != 0 || j0 < K + 2 || j0 + 7 + 4 >= rowsT || 2 * RING > PAD) { printf("bad shape\n"); return 1; }
     std::vector<float> hist((size_t)tiles * (K + PAD) * 64, 0.0f), table((size_t)rowsT * 8, 0.0f);
     srand(7);
     for (int t = 0; t < tiles; ++t)
