@@ -16,9 +16,12 @@ constexpr int PAD = 64;          // rows of zeros behind every history slab: the
 constexpr int RING = 16;         // source-day pairs in flight (8: 86 ns per source day, latency-bound)
 
 // hist: [tiles][K + PAD][64], table: [rowsT][8], out: [tiles][64 chains][64 = 8 days x 8 curves]
+template <bool TRANSPOSE>
 __global__ __launch_bounds__(64) void conv_mfma(const float* __restrict__ hist, const float* __restrict__ table,
                                                 float* __restrict__ out, int K, int rowsT, int j0, int reps) {
     extern __shared__ float lds[];
+    float* tr = lds + rowsT * 8;                                 // TRANSPOSE: [64 chains][65] floats behind the table
+    float keep = 0.0f;
     for (int i = threadIdx.x; i < rowsT * 8; i += 64) lds[i] = table[i];
     __syncthreads();
     const int l = threadIdx.x, half = l >> 5, n = l & 31;
@@ -61,6 +64,34 @@ __global__ __launch_bounds__(64) void conv_mfma(const float* __restrict__ hist, 
             }
             hp += 2 * RING * 64;
         }
+        if constexpr (TRANSPOSE) {
+            /* what the end of every 8-day block would do: the 64 sums of a chain from the MFMA layout
+             * (a lane holds one column of 16 chains per tile) to chain-per-lane, through LDS rows of 65 */
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        tr[(32 * mt + 8 * (v / 4) + 4 * half + (v % 4)) * 65 + 32 * nt + n] = acc[mt][nt][v];
+            __syncthreads();
+            float vals[64];
+#pragma unroll
+            for (int c = 0; c < 64; ++c) vals[c] = tr[l * 65 + c];
+            __syncthreads();
+            if (rep == reps - 1) {
+                float* o = out + (size_t)blockIdx.x * 64 * 64;
+#pragma unroll
+                for (int c = 0; c < 64; ++c) o[l * 64 + c] = vals[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 64; ++c) keep += vals[c];
+            }
+        }
+    }
+    if constexpr (TRANSPOSE) {
+        if (keep == 123.456f) out[0] = keep;                     // keeps the read-back alive
+        return;
     }
     float* o = out + (size_t)blockIdx.x * 64 * 64;
     for (int mt = 0; mt < 2; ++mt)
@@ -85,8 +116,10 @@ int main() {
     CK(hipMalloc(&dh, hist.size() * 4)); CK(hipMalloc(&dt, table.size() * 4)); CK(hipMalloc(&dout, (size_t)tiles * 4096 * 4));
     CK(hipMemcpy(dh, hist.data(), hist.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dt, table.data(), table.size() * 4, hipMemcpyHostToDevice));
-    const size_t shmem = (size_t)rowsT * 8 * 4;
-    hipLaunchKernelGGL(conv_mfma, dim3(tilesCheck), dim3(64), shmem, 0, dh, dt, dout, K, rowsT, j0, 1);
+    const size_t shmem = (size_t)rowsT * 8 * 4 + 64 * 65 * 4;
+  for (int variant = 0; variant < 2; ++variant) {
+    if (variant == 0) hipLaunchKernelGGL(conv_mfma<false>, dim3(tilesCheck), dim3(64), shmem, 0, dh, dt, dout, K, rowsT, j0, 1);
+    else hipLaunchKernelGGL(conv_mfma<true>, dim3(tilesCheck), dim3(64), shmem, 0, dh, dt, dout, K, rowsT, j0, 1);
     CK(hipGetLastError()); CK(hipDeviceSynchronize());
     std::vector<float> out((size_t)tilesCheck * 4096);
     CK(hipMemcpy(out.data(), dout, out.size() * 4, hipMemcpyDeviceToHost));
@@ -101,19 +134,21 @@ int main() {
                     const double err = fabs(got - s) / (fabs(s) + 1e-3);
                     if (err > worst) worst = err;
                 }
-    printf("lane maps: worst relative error against the host sum %.3g (%s)\n", worst, worst < 1e-4 ? "ok" : "WRONG");
+    printf("%s: worst relative error against the host sum %.3g (%s)\n", variant ? "after the LDS transpose" : "lane maps", worst, worst < 1e-4 ? "ok" : "WRONG");
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = 20;
     float ms = 0;
     for (int r = 0; r < 2; ++r) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(conv_mfma, dim3(tiles), dim3(64), shmem, 0, dh, dt, dout, K, rowsT, j0, reps);
+        if (variant == 0) hipLaunchKernelGGL(conv_mfma<false>, dim3(tiles), dim3(64), shmem, 0, dh, dt, dout, K, rowsT, j0, reps);
+        else hipLaunchKernelGGL(conv_mfma<true>, dim3(tiles), dim3(64), shmem, 0, dh, dt, dout, K, rowsT, j0, reps);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
     }
     const double pairs = (double)tiles * reps * K * 64 * 8;               // (chain, day, source day) triples
-    printf("1024 waves, %d source days x %d reps: %.3f ms  %.1f TFLOP/s issued (8 columns), %.1f useful (7 curves); "
-           "%.0f ns per source day per wave\n", K, reps, ms, pairs * 8 * 2 / ms / 1e9, pairs * 7 * 2 / ms / 1e9,
+    printf("%s1024 waves, %d source days x %d reps: %.3f ms  %.1f TFLOP/s issued (8 columns), %.1f useful (7 curves); "
+           "%.0f ns per source day per wave\n", variant ? "+ transpose per rep: " : "", K, reps, ms, pairs * 8 * 2 / ms / 1e9, pairs * 7 * 2 / ms / 1e9,
            ms * 1e6 / ((double)reps * K));
+  }
     return 0;
 }
