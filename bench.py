@@ -8,10 +8,12 @@ One "step" = one Target::step (mcmc.h:750-783) for EVERY chain of the workload: 
 compartment-model forward simulation, likelihood, prior, accept/reject.  Workload =
 BASELINE.json configs[2]: covid.h model, 65536 independent chains PER GPU, 365-day synthetic
 series, chain-sharded by chain-id range (weak scaling, no collective on the data path).
-The chains first run `--adjust` iterations of the reference's step-size adaptation (untimed,
-like the adjust phase that precedes sampling in MetropolisChain::run), then W warm-up steps.
-All inputs are resident in HBM before the timed region.  Arithmetic is FP64 as in the
-reference (`using Float = double`, mcmc.h:43).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(mcmc_amd/launcher.py), before this process touches HIP or torch; under torch.distributed.run the
+process is one of the ranks.  The chains first run `--adjust` iterations of the reference's
+step-size adaptation (untimed, like the adjust phase that precedes sampling in
+MetropolisChain::run), then W warm-up steps.  All inputs are resident in HBM before the timed
+region.  Arithmetic is FP64 as in the reference (`using Float = double`, mcmc.h:43).
 
 Prints ONE JSON line (rank 0).
 """
@@ -27,13 +29,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from mcmc_amd import covid_config as CC  # noqa: E402
-from mcmc_amd import hip as H  # noqa: E402
+from mcmc_amd import hip as H  # noqa: E402   (importing it loads nothing; H.lib() does)
+from mcmc_amd import launcher  # noqa: E402
 
 PEAK_FP64_VECTOR_TFLOPS = 78.6      # MI355X FP64 vector (FMA = 2 flop): 256 CU x 4 SIMD x 16 lanes/clk x 2 x 2.4 GHz
 PEAK_FP32_VECTOR_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (vector)"
 N_DATA = 365
 CHAINS_PER_GPU = 65536
-BETA_MILD, BETA_HIGH = 0.8, 2.5     # SURVEY 8d's (2, 10) overflow to NaN in the forward model
+STEPS_PER_LAUNCH = 16               # MCMC_STEPS_PER_LAUNCH of the library
+# SURVEY 8d names initial betas (2, 10) (covid.ipynb); with the current covid.h and the notebook's
+# constants that epidemic infects the whole population within the series and the forward model
+# overflows to NaN, so the synthetic counts are generated at (0.8, 2.5): DESIGN.md section 5.
+BETA_MILD, BETA_HIGH = 0.8, 2.5
 
 
 def build_workload(device, n_chains, first_chain_id, contract, n_data=N_DATA, precision="f64"):
@@ -42,13 +49,11 @@ def build_workload(device, n_chains, first_chain_id, contract, n_data=N_DATA, pr
     parameters perturbed by +-1 % (pcg32(0,0)), chain ids first_chain_id.."""
     dp = CC.ipynb_disease_params()
     R = H.make_response_tables(dp)                       # host, 10M trajectories, a few seconds
-    probe_holder = {}
 
     def forward(cfg, x):
         s = H.CovidSampler(cfg, R, device)
         dead = s.derive(x[None, :])[0, 7]
         s.close()
-        probe_holder["ok"] = True
         return dead
 
     cfg = CC.synthetic_config(n_data, forward, disease_params=dp, initial_beta_mild=BETA_MILD,
@@ -62,26 +67,51 @@ def build_workload(device, n_chains, first_chain_id, contract, n_data=N_DATA, pr
     return cfg, R, xs, sampler
 
 
-def cpu_baseline(cfg, R10, xs, stepsizes, contract, seconds=20.0):
-    """The oracle (a CPU port of the same path, oracle/mcmc_oracle.c) timed on this box's
-    host cores on a bounded sample of the same workload.  Reported, not the target."""
+def host_threads():
+    """Threads of the CPU leg: the cores this process may run on, capped by the box's per-GPU CPU
+    share (the GPU box exports OMP_NUM_THREADS = 16 for a one-GPU slot of a much larger machine and
+    asks worker pools to stay within it)."""
+    visible = len(os.sched_getaffinity(0))
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    used = min(visible, share) if share > 0 else visible
+    return max(1, min(used, 256)), visible
+
+
+def cpu_baseline(cfg, R10, xs, stepsizes, contract, seconds=12.0):
+    """The oracle (a CPU port of the same path, oracle/mcmc_oracle.c) timed on this box's host
+    cores on a bounded sample of the same workload, from the same adapted state.  Two figures
+    (SURVEY 8d): LEAN (response table shared by pointer -- the faster one, `value`) and FAITHFUL
+    (every proposal copies the 8.8 MB trajectory arrays and re-forms the running sums from them,
+    as DiseaseSpread::step's copy() does, covid.h:290,501,376-386).  Reported, not the target."""
     from oracle import oracle as O
     # ABI curve order -> oracle's 11-curve order (asymptomatic unused by the model)
     R11 = np.zeros((O.NCURVES, R10.shape[1]))
     for k, c in enumerate([3, 4, 0, 2, 5, 7, 6, 8, 9, 10]):
         R11[c] = R10[k]
-    m = O.Model(cfg, R11, contract=contract)
+    threads, visible = host_threads()
     tgt = O.make_target("temp", 1.0)
-    threads = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 64))
-    n_chains = 4 * threads
+    n_chains = min(4 * threads, xs.shape[0])
     ss = stepsizes[:n_chains]
-    cal = O.run_chains(m, tgt, xs[:n_chains], ss, 4, 0, 0, 1000, n_threads=threads)
-    per_step = cal["wall"] / 4
-    n_samples = int(max(8, min(40000, seconds / max(per_step, 1e-6))))
-    res = O.run_chains(m, tgt, xs[:n_chains], ss, n_samples, 0, 0, 1000, n_threads=threads)
-    return {"value": res["steps"] / res["wall"], "unit": "MH steps/s", "cores": threads, "kind": "port",
-            "sample": f"{n_chains} chains x {n_samples} steps of the same 365-day workload from the same adapted state "
-                      f"(oracle/mcmc_oracle.c, lean table, {threads} pthreads, {res['wall']:.1f} s)"}
+
+    def timed(model, label):
+        cal = O.run_chains(model, tgt, xs[:n_chains], ss, 2, 0, 0, 1000, n_threads=threads)
+        per_step = cal["wall"] / 2
+        n_samples = int(max(4, min(40000, seconds / max(per_step, 1e-6))))
+        res = O.run_chains(model, tgt, xs[:n_chains], ss, n_samples, 0, 0, 1000, n_threads=threads)
+        return res["steps"] / res["wall"], f"{n_chains} chains x {n_samples} steps, {res['wall']:.1f} s ({label})"
+
+    lean, lean_s = timed(O.Model(cfg, R11, contract=contract), "lean: table shared by pointer")
+    out = {"value": lean, "unit": "MH steps/s", "cores": threads, "cores_visible": visible, "kind": "port",
+           "sample": f"{lean_s} of the same 365-day workload from the same adapted state "
+                     f"(oracle/mcmc_oracle.c, -O3 -mavx2 -mfma, {threads} pthreads = the box's CPU share per GPU)"}
+    try:
+        grid = O.traj_generate(O.DiseaseParams(**{k: float(v) for k, v in CC.ipynb_disease_params().items()}))
+        faithful, faithful_s = timed(O.Model(cfg, O.traj_response(grid, R11.shape[1]), grid=grid, contract=contract,
+                                             faithful=1), "faithful: 8.8 MB copy per proposal + getDay sums")
+        out["faithful"] = {"value": faithful, "unit": "MH steps/s", "sample": faithful_s}
+    except Exception as e:                                # the faithful leg is extra information, never fatal
+        out["faithful"] = {"value": None, "error": repr(e)}
+    return out
 
 
 def ess_leg(cfg, R, device, contract, xs, stepsizes, first_id, n_steps, thinning):
@@ -108,37 +138,42 @@ def ess_finish(tot, n_saved, n_steps, thinning, ranks):
     names = ["betaMild", "betaHigh", "delay"]
     n = tot[0]
     rhat, _ = rhat_ess(tot[5:], 3, n_saved)                                          # Gelman-Rubin over all chains
-    return {"ess_per_step": {nm: float(tot[2 + j] / (n * n_steps)) for j, nm in enumerate(names)},
-            "acceptance": float(tot[1] / (n * n_steps)), "rhat": dict(zip(names, map(float, rhat))),
-            "sample": f"{int(n)} chains ({ranks} rank(s)) x {n_steps} steps after the adaptation, every {thinning}th point, "
-                      "Geyer initial positive sequence per chain, summed over chains; R-hat over all of them"}
+    converged = bool(np.all(np.isfinite(rhat)) and float(np.max(rhat)) < 1.1)
+    out = {"converged": converged, "acceptance": float(tot[1] / (n * n_steps)), "rhat": dict(zip(names, map(float, rhat))),
+           "sample": f"{int(n)} chains ({ranks} rank(s)) x {n_steps} steps after the adaptation, every {thinning}th point, "
+                     "Geyer initial positive sequence per chain, summed over chains; R-hat over all of them"}
+    if converged:
+        out["ess_per_step"] = {nm: float(tot[2 + j] / (n * n_steps)) for j, nm in enumerate(names)}
+    else:
+        out["note"] = ("R-hat >= 1.1: the chains have not reached stationarity in this stretch (a 358-dimensional "
+                       "random-walk sampler needs far more than a benchmark's steps), so no ESS/s is quoted")
+    return out
 
 
-def fast_mode_leg(cfg, R, device, xs, first_id, args):
-    """The same workload in the FAST arithmetic mode (renewal convolution in packed FP32,
-    include/mcmc_hip.h): its own adaptation, warm-up and timed steps.  Reported beside the FP64
-    figure, never as `value` -- it is not the reference's arithmetic."""
-    s = H.CovidSampler(cfg, R, device, precision="f32_model")
-    s.set_chains(xs, first_chain_id=first_id)
-    if args.adjust > 0:
-        s.run(0, 0, args.adjust, 1000000)
+def side_leg(cfg, R, device, start, first_id, args, precision, contract):
+    """The same workload under another arithmetic, from the main leg's adapted state (parameters and
+    step sizes; chain ids as there): warm-up and timed steps of its own.  Reported beside the
+    headline, never as `value`."""
+    cfg2 = dict(cfg)
+    cfg2["contract"] = contract
+    s = H.CovidSampler(cfg2, R, device, precision=precision)
+    s.set_chains(start[0], stepsizes=start[1], first_chain_id=first_id)
+    steps = max(STEPS_PER_LAUNCH, args.steps // 2 // STEPS_PER_LAUNCH * STEPS_PER_LAUNCH)
     s.step(args.warmup, 1.0, True)
     s.pair_count(reset=True)
     t0 = s.last_timing()
     w0 = time.perf_counter()
-    s.step(args.steps, 1.0, True)
+    s.step(steps, 1.0, True)
     wall = time.perf_counter() - w0
     t1 = s.last_timing()
-    pairs = s.pair_count()
-    n = xs.shape[0]
+    pairs, pairs_exec = s.pair_count(), s.executed_pair_count()
+    n = start[0].shape[0]
     s.close()
     ksec, launches = t1["step_kernel_s"] - t0["step_kernel_s"], t1["launches"] - t0["launches"]
-    flops = 16.0 * pairs + (10.0 * N_DATA + 7.0 * cfg["nB"]) * n * args.steps
-    return {"value": n * args.steps / wall, "unit": "MH steps/s", "ms_per_step": 1e3 * wall / args.steps,
-            "dtype": "f32 packed (renewal convolution) + f64 (everything else)",
+    flops = 16.0 * pairs + (10.0 * N_DATA + 7.0 * cfg["nB"]) * n * steps
+    return {"value": n * steps / wall, "unit": "MH steps/s", "steps": steps, "ms_per_step": 1e3 * wall / steps,
             "kernel_ms_per_launch": 1e3 * ksec / max(launches, 1), "achieved": flops / ksec / 1e12,
-            "peak": PEAK_FP32_VECTOR_TFLOPS, "unit_roofline": "TFLOP/s", "frac": flops / ksec / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
-            "parity": "statistical (tests/test_gpu_fast_mode.py), not bit-exact: never the headline value"}
+            "executed_tflops": 14.0 * pairs_exec / ksec / 1e12, "unit_roofline": "TFLOP/s"}
 
 
 def main():
@@ -152,6 +187,7 @@ def main():
                     help="adjust-phase iterations (20 MH steps each, mcmc.h:1083-1119) run untimed before the warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-leg", action="store_true", help="skip the FP32 fast-mode leg (N=1 only)")
+    ap.add_argument("--no-strict-leg", action="store_true", help="skip the strict (no FMA contraction) leg (N=1 only)")
     ap.add_argument("--precision", default="f64", choices=["f64", "f32_model"],
                     help="arithmetic of the MAIN leg; f32_model (fast mode) is for profiling that kernel only: "
                          "the line then says dtype f32+f64 and is not the headline metric")
@@ -166,12 +202,24 @@ def main():
     ap.add_argument("--device", type=int, default=None, help="HIP ordinal for every rank (default: LOCAL_RANK)")
     args = ap.parse_args()
 
+    # ---- one process per GPU: become the launcher if this is a plain `--gpus N` call (nothing in
+    # this process has touched HIP or torch yet) ----
+    overlays = launcher.plan_launch(args.gpus, os.environ)
+    if overlays is not None:
+        raise SystemExit(launcher.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], overlays))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     import torch
     device = args.device if args.device is not None else (local_rank if world > 1 else 0)
+    n_dev = H.lib().mcmc_hip_device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
+    if device >= n_dev:
+        raise SystemExit(f"bench.py: rank {rank} wants HIP device {device} but only {n_dev} are visible "
+                         f"(--gpus {args.gpus}); use --device to rehearse several ranks on one card")
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(device)
@@ -179,8 +227,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group("gloo")
-    if H.lib().mcmc_hip_device_count() < 1:
-        raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
 
     n_chains = args.chains_per_gpu
     first_id = 1 + rank * n_chains                       # contiguous chain-id ranges
@@ -200,8 +246,7 @@ def main():
         temps = np.geomspace(1.0, args.ladder_tmax, args.ladder)
         s.set_ladder(temps, swap_seed=1, first_ladder=rank * (n_chains // args.ladder))
     s.step(args.warmup, 1.0, True)
-    n_keep = max(256, min(args.ess_chains, n_chains))
-    cpu_start = (s.params()[:n_keep].copy(), s.stepsizes()[:n_keep].copy())
+    adapted = (s.params(), s.stepsizes())                # start of the CPU leg and the side legs
     s.pair_count(reset=True)
     t_before = s.last_timing()
     diag_before = s.diagnostics()                        # additive sums of this shard (untimed)
@@ -230,9 +275,9 @@ def main():
 
     # ESS / R-hat leg on every rank (its first --ess-chains chains), pieces summed by one more all-reduce
     ess_tot = None
-    if args.ess_chains > 0 and not args.ladder and not (args.precision != "f64"):
+    if args.ess_chains > 0 and not args.ladder and not fast_main:
         ne = min(args.ess_chains, n_chains)
-        pieces, ess_saved = ess_leg(cfg, R, device, args.contract, cpu_start[0][:ne], cpu_start[1][:ne], first_id,
+        pieces, ess_saved = ess_leg(cfg, R, device, args.contract, adapted[0][:ne], adapted[1][:ne], first_id,
                                     args.ess_steps, 5)
         ess_tot = allreduce_sum(pieces)
 
@@ -243,16 +288,25 @@ def main():
         ksec = t_after["step_kernel_s"] - t_before["step_kernel_s"]
         launches = t_after["launches"] - t_before["launches"]
         pairs = s.pair_count()                            # sum over chains/steps, SURVEY 8d work unit
+        pairs_exec = s.executed_pair_count()
         nB = cfg["nB"]
         flops = 16.0 * pairs + (10.0 * N_DATA + 7.0 * nB) * n_chains * args.steps
+        flops_exec = 14.0 * pairs_exec                    # the multiply-adds the kernel ran: 7 families, visible days
         achieved = flops / ksec / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and not fast_main:
+        # HBM-side traffic: not measured in this run (PMC counters need rocprofv3); taken from the
+        # committed profile of the same kernel and scaled per chain-step, with its source named
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic_fast_mode.json" if fast_main else "traffic_latest.json")
+        if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                per_chain_step = tj["hbm_bytes_per_launch"] / (tj.get("chains", CHAINS_PER_GPU) * tj.get("steps_per_launch", STEPS_PER_LAUNCH))
+                traffic = per_chain_step * n_chains * args.steps / max(launches, 1)
+                traffic_src = {"from_profile": os.path.relpath(tpath, ROOT), "tag": tj.get("tag"),
+                               "profiled_launch": f"{tj.get('steps_per_launch', STEPS_PER_LAUNCH)} steps x {tj.get('chains', CHAINS_PER_GPU)} chains",
+                               "scaled_to": f"{args.steps / max(launches, 1):g} steps x {n_chains} chains per launch (bytes are per chain-step)"}
             except Exception:
-                traffic = None
+                traffic, traffic_src = None, None
         out = {
             "metric": "MH steps/sec (whole node) on covid model, 64k chains; ESS/sec vs CPU TBB",   # BASELINE.json's string; ESS/s is in "ess"
             "value": value, "unit": "MH steps/s", "n_gpus": world, "steps": args.steps,
@@ -270,11 +324,18 @@ def main():
                        "parallelism": f"chain-shard x{world}"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "kernel": "mh_step_kernel",
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "mh_step_kernel",
                          "kernel_ms_per_launch": 1e3 * ksec / max(launches, 1), "launches": launches,
                          "steps_per_launch": args.steps / max(launches, 1),
                          "algorithmic_flops_per_launch": flops / max(launches, 1),
-                         "frac_of_fp32_vector_peak": achieved / PEAK_FP32_VECTOR_TFLOPS},
+                         "frac_of_fp32_vector_peak": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                         # what the kernel's FMA pipe really did: the reference-algorithmic figure above counts 8
+                         # compartments over maxDelay+nPredict+nData days, the kernel runs 7 over maxDelay+nData
+                         "executed": {"tflops": flops_exec / ksec / 1e12, "frac": flops_exec / ksec / 1e12 / peak,
+                                      "flops_per_launch": flops_exec / max(launches, 1),
+                                      "what": "14 flop x (day, lag) pairs actually run (7 accumulator families, days "
+                                              "the log-likelihood can see); capacity corrections, proposal and the "
+                                              "sequential day loop not counted"}},
         }
         n_all, dim = tot[1], cfg["dim"]
 
@@ -286,19 +347,33 @@ def main():
                               **{nm: mean_sd(4 + 2 * (dim - 3 + j)) for j, nm in enumerate(["betaMild_mean_sd", "betaHigh_mean_sd", "delay_mean_sd"])},
                               "how": f"mcmc_hip_diagnostics per rank, one all-reduce(SUM) of {len(local)} doubles "
                                      f"({'RCCL' if (dist is not None and args.backend == 'nccl') else 'single rank' if dist is None else 'gloo'})"}
+        n_keep = max(256, min(4096, n_chains))
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(cfg, R, cpu_start[0], cpu_start[1], args.contract)
+            cb = cpu_baseline(cfg, R, adapted[0][:n_keep], adapted[1][:n_keep], args.contract)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = value / cb["value"]
-        if world == 1 and not args.no_fast_leg and not args.ladder and args.contract and not fast_main:
-            out["fp32_fast_mode"] = fast_mode_leg(cfg, R, device, xs, first_id, args)
-            out["fp32_fast_mode"]["speedup_over_f64"] = out["fp32_fast_mode"]["value"] / value
+        side = world == 1 and not args.ladder and not fast_main
+        if side and args.contract and not args.no_strict_leg:
+            # the C++ source semantics: every projection term a multiply and an add (cfg.contract = 0)
+            out["strict"] = side_leg(cfg, R, device, adapted, first_id, args, "f64", 0)
+            out["strict"].update({"fp_contract": "strict", "dtype": "f64", "peak": PEAK_FP64_VECTOR_TFLOPS,
+                                  "frac": out["strict"]["achieved"] / PEAK_FP64_VECTOR_TFLOPS,
+                                  "slowdown_vs_fma": value / out["strict"]["value"],
+                                  "parity": "bit-exact against the oracle built with contract=0 (tests/test_gpu_parity.py)"})
+        if side and args.contract and not args.no_fast_leg:
+            out["fp32_fast_mode"] = side_leg(cfg, R, device, adapted, first_id, args, "f32_model", 1)
+            out["fp32_fast_mode"].update({"dtype": "f32 packed (renewal convolution) + f64 (everything else)",
+                                          "peak": PEAK_FP32_VECTOR_TFLOPS,
+                                          "frac": out["fp32_fast_mode"]["achieved"] / PEAK_FP32_VECTOR_TFLOPS,
+                                          "speedup_over_f64": out["fp32_fast_mode"]["value"] / value,
+                                          "parity": "statistical (tests/test_gpu_fast_mode.py), not bit-exact: never the headline value"})
         if ess_tot is not None:
             e = ess_finish(ess_tot, ess_saved, args.ess_steps, 5, world)
-            worst = min(e["ess_per_step"].values())
-            e["gpu_ess_per_s"] = worst * value            # slowest-mixing of the three coordinates, whole job
-            if "cpu_baseline" in out:
-                e["cpu_ess_per_s"] = worst * out["cpu_baseline"]["value"]
+            if e["converged"]:
+                worst = min(e["ess_per_step"].values())
+                e["gpu_ess_per_s"] = worst * value        # slowest-mixing of the three coordinates, whole job
+                if "cpu_baseline" in out:
+                    e["cpu_ess_per_s"] = worst * out["cpu_baseline"]["value"]
             out["ess"] = e
         print(json.dumps(out), flush=True)
     s.close()

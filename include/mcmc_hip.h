@@ -189,9 +189,15 @@ int mcmc_hip_diagnostics(mcmc_hip_ctx* ctx, double* out);
  * step kernel and the number of its launches (for roofline accounting). */
 int mcmc_hip_last_timing(mcmc_hip_ctx* ctx, double* adjust_s, double* sampling_s,
                          double* step_kernel_s, int64_t* step_kernel_launches);
-/* algorithmic (day,lag) pairs the step kernel executed since the counter was reset,
- * summed over chains: each pair is one multiply-add per compartment (covid.h:384). */
+/* algorithmic (day,lag) pairs of the evaluations the step kernel made since the counter was
+ * reset, summed over chains: what the reference performs over its full horizon, one multiply-add
+ * per compartment and pair (covid.h:384), lags cut at traj.nDays (covid.h:378). */
 int mcmc_hip_pair_count(mcmc_hip_ctx* ctx, double* pairs_out, int32_t reset);
+/* (day,lag) pairs the step kernel actually ran for the chains since the reset: only the days
+ * the log-likelihood can see (maxDelay+nData of the reference's maxDelay+nPredict+nData,
+ * covid.h:297,488-492), seven accumulator families each (asymptomatic == mild, covid.h:406).
+ * Either call with reset != 0 clears BOTH counters. */
+int mcmc_hip_executed_pair_count(mcmc_hip_ctx* ctx, double* pairs_out, int32_t reset);
 
 /* --- tempering ladder with swap exchange (EXTENSION: BASELINE.json configs[3]; the reference has
  * no replica exchange -- its TempTarget, mcmc.h:797-808, only fixes one temperature per run).

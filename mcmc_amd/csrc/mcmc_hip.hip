@@ -109,11 +109,6 @@ struct mcmc_hip_ctx {
     DevBuf<uint64_t> dSwapRng;
     DevBuf<unsigned long long> dSwapAcc;
     unsigned long long swapRounds[2] = {0, 0};
-    /* cooperative pair of waves per tile (MCMC_HIP_COOP=1) */
-    bool coop = false;
-    /* the two passes of an evaluation in two waves of a SIMD (MCMC_HIP_SPLIT=1) */
-    bool split = false;
-    DevBuf<int> dCoopErr;
     /* scratch */
     DevBuf<double> dBetas;
     DevBuf<int> dFlags;
@@ -271,39 +266,7 @@ int run_eval_current(mcmc_hip_ctx* c) {
     return launch_chain_kernel(c, eval_kernel<MCMC_T, false>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
 }
 
-template <typename K>
-int launch_coop(mcmc_hip_ctx* c, K kernel, int nSteps, const double* dBetas, const int* dFlags, int slot0) {
-    const unsigned grid = (unsigned)((c->nTiles + MCMC_WAVES_PER_BLOCK - 1) / MCMC_WAVES_PER_BLOCK);
-    size_t shmem = coop_sync_offset(c->M, MCMC_T) + MCMC_COOP_SYNC_BYTES;
-    if (shmem > kLdsMax)
-        return fail(MCMC_HIP_EINVAL, "the series is too long for the LDS image (%zu B > %zu B)", shmem, kLdsMax);
-    if (shmem < kLdsSolo) shmem = kLdsSolo;            /* 8 waves per workgroup: one workgroup per CU */
-    if (!c->dCoopErr.p) {
-        if (int r = c->dCoopErr.alloc(1)) return r;
-        HIP_TRY(hipMemsetAsync(c->dCoopErr.p, 0, sizeof(int), c->stream));
-    }
-    HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(MCMC_COOP_BLOCK), shmem, c->stream, c->M, c->S, nSteps, dBetas, dFlags,
-                       slot0, c->dCoopErr.p);
-    HIP_TRY(hipGetLastError());
-    int h = 0;
-    HIP_TRY(hipMemcpyAsync(&h, c->dCoopErr.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (h != 0) return fail(MCMC_HIP_EHIP, "cooperative step kernel: a wave ran into the hand-over spin limit");
-    return 0;
-}
-
 int launch_steps(mcmc_hip_ctx* c, int nSteps, const double* dBetas, const int* dFlags, int slot0) {
-    if (c->split && c->precision == MCMC_HIP_PRECISION_F64) {
-        if (c->dHn.n < (size_t)2 * c->histRows * c->nP)
-            return fail(MCMC_HIP_ESTATE, "split kernel: the history buffers hold one set only");
-        if (c->cfg.contract) return launch_coop(c, mh_step_split_kernel<MCMC_T, true>, nSteps, dBetas, dFlags, slot0);
-        return launch_coop(c, mh_step_split_kernel<MCMC_T, false>, nSteps, dBetas, dFlags, slot0);
-    }
-    if (c->coop) {
-        if (c->cfg.contract) return launch_coop(c, mh_step_coop_kernel<MCMC_T, true>, nSteps, dBetas, dFlags, slot0);
-        return launch_coop(c, mh_step_coop_kernel<MCMC_T, false>, nSteps, dBetas, dFlags, slot0);
-    }
     if (c->precision == MCMC_HIP_PRECISION_F32_MODEL)
         return launch_chain_kernel(c, mh_step_kernel<MCMC_T, true, 1>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0);
     if (c->cfg.contract)
@@ -439,9 +402,6 @@ static int init_ctx(mcmc_hip_ctx* c, const mcmc_covid_config* cfg, int device) {
     c->cfg.disc_fixed = c->discFixed.data();
     c->device = device;
     HIP_TRY(hipDeviceGetAttribute(&c->nCU, hipDeviceAttributeMultiprocessorCount, device));
-    { const char* e = std::getenv("MCMC_HIP_COOP"); c->coop = e && std::atoi(e) != 0; }
-    { const char* e = std::getenv("MCMC_HIP_SPLIT"); c->split = e && std::atoi(e) != 0; }
-    if (c->split && c->coop) return fail(MCMC_HIP_EINVAL, "create: MCMC_HIP_SPLIT and MCMC_HIP_COOP exclude each other");
     c->size = cfg->max_delay + cfg->n_predict + cfg->n_data;          /* covid.h:297 */
     c->nB = cfg->n_data - cfg->fix_behavior_in_advance;               /* covid.h:299 */
     c->dim = c->nB + cfg->n_disc + 3;
@@ -567,7 +527,6 @@ int mcmc_hip_set_precision(mcmc_hip_ctx* c, int32_t mode) try {
     if (mode == MCMC_HIP_PRECISION_F32_MODEL) {
         if (!c->haveTables) return fail(MCMC_HIP_ESTATE, "set_precision: call set_tables first");
         if (!c->cfg.contract) return fail(MCMC_HIP_EINVAL, "set_precision: the fast mode needs cfg.contract = 1");
-        if (c->coop || c->split) return fail(MCMC_HIP_EINVAL, "set_precision: the fast mode has no cooperative / split kernel");
     }
     c->precision = mode;
     c->haveChains = false;             /* log-likelihoods of the other arithmetic are not comparable */
@@ -576,9 +535,8 @@ int mcmc_hip_set_precision(mcmc_hip_ctx* c, int32_t mode) try {
 
 static int alloc_work(mcmc_hip_ctx* c, long long nP) {
     /* history + LL scratch for nP lanes; contents are fully rewritten by every evaluation */
-    const size_t sets = c->split ? 2 : 1;          /* SPLIT: a history set per pass (mh_step_split_kernel) */
-    if (int r = c->dHn.alloc(sets * (size_t)c->histRows * nP)) return r;
-    if (int r = c->dHe.alloc(sets * (size_t)c->histRows * nP)) return r;
+    if (int r = c->dHn.alloc((size_t)c->histRows * nP)) return r;
+    if (int r = c->dHe.alloc((size_t)c->histRows * nP)) return r;
     if (int r = c->dD1s.alloc((size_t)2 * c->cfg.n_data * nP)) return r;
     HIP_TRY(hipMemsetAsync(c->dHn.p, 0, c->dHn.n * sizeof(double), c->stream));
     HIP_TRY(hipMemsetAsync(c->dHe.p, 0, c->dHe.n * sizeof(double), c->stream));
@@ -604,7 +562,7 @@ int mcmc_hip_set_chains(mcmc_hip_ctx* c, int64_t n_chains, const double* params,
     if (int r = c->dStepsize.alloc(nP)) return r;
     if (int r = c->dRng.alloc(2 * nP)) return r;
     if (int r = c->dNAccept.alloc(nP)) return r;
-    if (int r = c->dPairs.alloc(nP)) return r;
+    if (int r = c->dPairs.alloc(2 * nP)) return r;
     if (int r = c->dMean.alloc((size_t)dim * nP)) return r;
     c->dRecLL.release(); c->dRecSamples.release();
     c->nSaved = 0; c->nSavedCap = 0; c->recSamples = false;
@@ -626,7 +584,7 @@ int mcmc_hip_set_chains(mcmc_hip_ctx* c, int64_t n_chains, const double* params,
     HIP_TRY(hipMemcpyAsync(c->dMean.p, S.params, (size_t)dim * nP * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(S.params + (size_t)dim * nP, 0, (size_t)dim * nP * sizeof(double), c->stream));
     HIP_TRY(hipMemsetAsync(S.nAccept, 0, nP * sizeof(int), c->stream));
-    HIP_TRY(hipMemsetAsync(S.pairs, 0, nP * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(S.pairs, 0, 2 * nP * sizeof(unsigned long long), c->stream));
 
     std::vector<double> ss(nP, 1.0);
     std::vector<uint64_t> rng(2 * nP);
@@ -1004,15 +962,23 @@ int mcmc_hip_debug_phase_cycles(mcmc_hip_ctx* c, double* out, int32_t reset) try
     return 0;
 } MCMC_ABI_GUARD
 
-int mcmc_hip_pair_count(mcmc_hip_ctx* c, double* pairs_out, int32_t reset) try {
-    if (int r = need_chains(c, pairs_out)) return r;
-    std::vector<unsigned long long> h(c->nP);
+/* sums one of the two per-chain work counters ([nTiles][2][64]: algorithmic, executed) */
+static int work_count(mcmc_hip_ctx* c, int which, double* out, int32_t reset) {
+    if (int r = need_chains(c, out)) return r;
+    std::vector<unsigned long long> h(2 * c->nP);
     HIP_TRY(hipMemcpy(h.data(), c->S.pairs, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     double s = 0;
-    for (long long i = 0; i < c->nChains; ++i) s += (double)h[i];
-    *pairs_out = s;
+    for (long long i = 0; i < c->nChains; ++i)
+        s += (double)h[(size_t)(i / MCMC_WAVE) * 2 * MCMC_WAVE + (size_t)which * MCMC_WAVE + (size_t)(i % MCMC_WAVE)];
+    *out = s;
     if (reset) HIP_TRY(hipMemset(c->S.pairs, 0, h.size() * sizeof(unsigned long long)));
     return 0;
+}
+int mcmc_hip_pair_count(mcmc_hip_ctx* c, double* pairs_out, int32_t reset) try {
+    return work_count(c, 0, pairs_out, reset);
+} MCMC_ABI_GUARD
+int mcmc_hip_executed_pair_count(mcmc_hip_ctx* c, double* pairs_out, int32_t reset) try {
+    return work_count(c, 1, pairs_out, reset);
 } MCMC_ABI_GUARD
 
 /* ------------------------------------------------------------------ toy targets ---- */

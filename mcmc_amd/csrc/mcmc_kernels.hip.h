@@ -558,57 +558,33 @@ __device__ __forceinline__ void lag_tail(double (&acc)[A_NPOS][T], const double 
 /* rows of the history arrays are offset so that index k = -HOFF is row 0 */
 #define MCMC_HOFF(T) (2 * (T))
 
-/* ------------------------------------------------ cooperative pair of waves (COOP) ---- */
-/* Two waves of one workgroup work on ONE tile of 64 chains, so that every SIMD holds two
- * waves (a lone wave issues an FP64 multiply-add only every ~5 cycles).  The 8-day blocks of a
- * pass alternate between them: role r owns the blocks with (block index & 1) == r.  For its
- * block b a wave first runs the lag chunks whose source days are final (chunks 0..b-2, they
- * end before the partner's block b-1), then waits until the partner has published block b-1,
- * and finishes with the last chunk, the tail and the sequential days.  Role 0 also does what
- * is per chain and step: proposal, likelihood pass, accept.
- * The pair talks through four LDS words: [0] blocks published (monotone over the launch),
- * [1] proposals published (monotone), [2] keLo, [3] keHi (the day range with capacity
- * corrections of the current pass).  History rows travel through global memory; the waves
- * share the CU's vector L1, so a release/acquire pair at workgroup scope orders them. */
-#ifndef MCMC_COOP_SPIN_LIMIT
-#define MCMC_COOP_SPIN_LIMIT (1 << 22)
-#endif
-struct PairSync {
-    volatile int* w;
-    int role;
-    int* err;              /* global error word: set if a wait ran into the spin limit */
+/* Work accounting of one evaluation, per chain.  `algo` = the (day, lag) pairs the reference
+ * performs over its full horizon `size` (the SURVEY 8d work unit: 8 compartments, 16 flop per
+ * pair); `exec` = the pairs this kernel's sampling path executes for the chain (days up to
+ * maxDelay+nData only, 7 accumulator families = 14 flop per pair).  Both follow project()'s
+ * d < nDays cut-off (covid.h:378): a source day reaches at most nLag later days. */
+struct WorkCount {
+    unsigned long long algo, exec;
 };
-__device__ __forceinline__ void pair_signal(const PairSync& ps, int idx, int v) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    ps.w[idx] = v;
+__device__ __forceinline__ long long tri_capped(long long m, long long cap) {
+    return m <= cap ? m * (m + 1) / 2 : cap * (cap + 1) / 2 + (m - cap) * cap;
 }
-__device__ __forceinline__ void pair_wait(const PairSync& ps, int idx, int v) {
-    int spins = 0;
-    while (__builtin_amdgcn_readfirstlane(ps.w[idx]) < v) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > MCMC_COOP_SPIN_LIMIT) { *ps.err = 1; break; }    /* never hang the GPU */
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+__device__ __forceinline__ void count_work(const DevModel& M, int start, WorkCount& work) {
+    const long long cap = M.nLagRows;
+    const long long a1 = M.size - min(start + 1, M.size), a0 = M.size - min(start, M.size);
+    const long long e1 = M.simDays - min(start + 1, M.simDays), e0 = M.simDays - min(start, M.simDays);
+    work.algo += (unsigned long long)(tri_capped(a1, cap) + tri_capped(a0, cap));
+    work.exec += (unsigned long long)(tri_capped(e1, cap) + tri_capped(e0, cap));
 }
 
 /*
- * DiseaseSpread::eval (covid.h:325-496) for the chain of this lane.  Returns loglike.
- * pairs += number of (day,lag) pairs the reference performs for this evaluation over the
- * full horizon `size` (the SURVEY 8d work unit).
+ * DiseaseSpread::eval (covid.h:325-496) for the chain of this lane.  Returns loglike and adds
+ * the evaluation's work to `work`.
  */
-template <int T, bool FUSE, bool DERIVE, bool COOP = false, bool SPLIT = false>
+template <int T, bool FUSE, bool DERIVE>
 __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& lds, const WaveBases& B,
-                                             const LaneScalars& lp, unsigned lane, unsigned long long& pairs,
-                                             PhaseClock& pc, const PairSync* ps = nullptr, int* passCounter = nullptr,
-                                             int onlyShift = 0) {
-    static_assert(!(COOP && DERIVE), "the derive kernel is single-wave");
-    static_assert(!(SPLIT && (COOP || DERIVE)), "SPLIT is a mode of its own");
-    /* SPLIT (mh_step_split_kernel): this call runs ONE of the two passes, `onlyShift`, and leaves the
-     * likelihood sums to loglike_passes(); it is built for 256 registers (two waves per SIMD), so
-     * what the sequential part needs from memory is loaded per day instead of per block and the
-     * next block's window is requested after the day loop -- the partner wave hides the waits. */
-    constexpr bool LEAN = SPLIT;          /* the next block's window is requested after the day loop */
-    constexpr bool LEAN_DAYS = false;     /* per-day loads in the day loop: measured 10x slower days, off */
+                                             const LaneScalars& lp, unsigned lane, WorkCount& work,
+                                             PhaseClock& pc) {
     const int md = M.md;
     const int horizon = DERIVE ? M.size : M.simDays;
     const double* xdisc_u = B.x_u + M.nB * MCMC_WAVE;
@@ -618,13 +594,10 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
     const double frac = (double)md - lp.delay - (double)start;      /* covid.h:332 */
     /* memory safety: every day index below derives from these clamped values */
     start = min(max(start, 0), horizon);
-    if (!SPLIT || onlyShift == 0) {
-        long long m1 = M.size - min(start + 1, M.size), m0 = M.size - min(start, M.size);
-        pairs += (unsigned long long)(m1 * (m1 + 1) / 2 + m0 * (m0 + 1) / 2);
-    }
+    count_work(M, start, work);
 
 #pragma unroll 1
-    for (int shift = SPLIT ? onlyShift : 1; shift >= (SPLIT ? onlyShift : 0); --shift) {   /* covid.h:335 */
+    for (int shift = 1; shift >= 0; --shift) {                      /* covid.h:335 */
         const double w = (double)(1 - shift) * (1.0 - frac) + (double)shift * frac; /* covid.h:333 */
         const int s = min(start + shift, horizon);
         int ws = wave_min_i32(s);
@@ -635,17 +608,12 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
         /* zero the 2T history rows below ws (read as k < ws by the first blocks) and plant
          * patient zero (covid.h:339): n_s = 1, n_k = 0 for k < s */
         double ncur = (s == ws) ? 1.0 : 0.0;
-        int fbase = 0;                        /* COOP: value of the block counter before this pass */
-        if constexpr (COOP) fbase = ((*passCounter)++) * 4096;
-        if (!COOP || ps->role == 0) {
 #pragma unroll 1
-            for (int k = ws - 2 * T; k < ws; ++k) {
-                B.hn_u[(k + MCMC_HOFF(T)) * MCMC_WAVE + lane] = 0.0;
-                B.he_u[(k + MCMC_HOFF(T)) * MCMC_WAVE + lane] = 0.0;
-            }
-            B.hn_u[(ws + MCMC_HOFF(T)) * MCMC_WAVE + lane] = ncur;
-            if constexpr (COOP) { ps->w[2] = 0x7fffffff; ps->w[3] = -1; }   /* published with block 0 */
+        for (int k = ws - 2 * T; k < ws; ++k) {
+            B.hn_u[(k + MCMC_HOFF(T)) * MCMC_WAVE + lane] = 0.0;
+            B.he_u[(k + MCMC_HOFF(T)) * MCMC_WAVE + lane] = 0.0;
         }
+        B.hn_u[(ws + MCMC_HOFF(T)) * MCMC_WAVE + lane] = ncur;
 
         if constexpr (DERIVE) {
             /* days before the wave's first start: all buffers are zero there */
@@ -685,9 +653,7 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
             double beh[T];
             /* ------------- phase A: sources k < j0, lags descending = k ascending */
             const int b = (j0 - ws) / T;                     /* full chunks of T lags */
-            if constexpr (COOP) { if ((b & 1) != ps->role) continue; }   /* the partner's block */
-            /* chunks [c0, bRun) run now; COOP keeps the last one for after the hand-over */
-            const int bRun = COOP ? max(b - 1, 0) : b;
+            const int bRun = b;
             bool anyE = keHi >= keLo;
             int Lc = j0 - ws + T - 1;                        /* first lag of chunk 0 */
             int c0 = 0;
@@ -795,7 +761,6 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
             RowRegs RR;
             if constexpr (FUSE && T == 8 && MCMC_DPP_ROWS) RR = load_row_regs(lds, lane);
             double pcfv[T];
-            if constexpr (!LEAN_DAYS) {
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const int bi = min(max(j0 + t - md, 0), M.nB - 1);
@@ -807,44 +772,8 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                 const double dv = xdisc_u[max(sg, 0) * MCMC_WAVE + lane];
                 pcfv[t] = sg >= 0 ? dv : 1.0;
             }
-            }
             pc.stamp(PH_CHUNKS);
-            if constexpr (COOP) {
-                /* hand-over: the partner has published block b-1 (days j0-T .. j0-1, n_{j0} and
-                 * its part of the correction range); now the last chunk and the tail can run */
-                if (b > 0) pair_wait(*ps, 0, fbase + b);
-                pc.stamp(PH_WAIT);
-                keLo = min(keLo, __builtin_amdgcn_readfirstlane(ps->w[2]));
-                keHi = max(keHi, __builtin_amdgcn_readfirstlane(ps->w[3]));
-                anyE = keHi >= keLo;
-                const double* lrow = B.hn_u + (j0 - 2 * T + 1 + MCMC_HOFF(T)) * MCMC_WAVE;
-                const double* erow = B.he_u + (j0 - 2 * T + 1 + MCMC_HOFF(T)) * MCMC_WAVE;
-                double LN[T];                 /* n of the days j0-T+1 .. j0 */
-#pragma unroll
-                for (int q = 0; q < T; ++q) LN[q] = lrow[(q + T) * MCMC_WAVE + lane];
-                if (b >= 1 && c0 <= b - 1) {                 /* chunk b-1: lags 2T-1 .. T */
-                    double LW[T];
-#pragma unroll
-                    for (int q = 0; q < T; ++q) LW[q] = lrow[q * MCMC_WAVE + lane];
-                    if (anyE && j0 - 2 * T + 1 <= keHi && j0 - 1 >= keLo) {
-                        double LEW[T], LEN[T];
-#pragma unroll
-                        for (int q = 0; q < T; ++q) {
-                            LEW[q] = erow[q * MCMC_WAVE + lane];
-                            LEN[q] = erow[(q + T) * MCMC_WAVE + lane];
-                        }
-                        double4_t rn = lds_row4(lds.Rneg, Lc);
-                        lag_chunk_e<T, FUSE>(acc, LW, LN, LEW, LEN, r, rn, MCMC_TAB(lds, M), lds.Rneg, Lc, lrow, erow, lane);
-                    } else {
-                        lag_chunk<T, FUSE>(acc, LW, LN, r, MCMC_TAB(lds, M), Lc, lrow, lane);
-                    }
-                }
-                if (anyE && j0 - T + 1 <= keHi && j0 - 1 >= keLo)
-                    lag_tail<T, FUSE, true>(acc, LN, lds.Rpos, lds.Rneg, ebase + b * T * MCMC_WAVE, lane, RR);
-                else
-                    lag_tail<T, FUSE, false>(acc, LN, lds.Rpos, lds.Rneg, nullptr, lane, RR);
-                ncur = LN[T - 1];
-            } else {
+            {
                 /* the tail reads source days [j0-T+1, j0-1] */
                 if (anyE && j0 - T + 1 <= keHi && j0 - 1 >= keLo)
                     lag_tail<T, FUSE, true>(acc, WA, lds.Rpos, lds.Rneg, ebase + b * T * MCMC_WAVE, lane, RR);
@@ -855,7 +784,7 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
             /* the window registers are free now: request the first window of the NEXT block
              * before the sequential phase B, unless this block is about to write into it
              * (only the first block of a shift does: its days are ws .. ws+T-1 <= a0+2T-1) */
-            if (!LEAN && b > 0) {
+            if (b > 0) {
 #pragma unroll
                 for (int q = 0; q < T; ++q) {
                     WA[q] = hbase[q * MCMC_WAVE + lane];
@@ -919,13 +848,6 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                     }
                 }
                 /* piecewise-constant factor and behaviour (covid.h:432-454) */
-                if constexpr (LEAN_DAYS) {
-                    const int bi = min(max(i - md, 0), M.nB - 1);
-                    beh[t] = B.x_u[bi * MCMC_WAVE + lane];
-                    const int sg = __builtin_amdgcn_readfirstlane(lds.seg[i]);
-                    const double dv = xdisc_u[max(sg, 0) * MCMC_WAVE + lane];
-                    pcfv[t] = sg >= 0 ? dv : 1.0;
-                }
                 const double pcf = pcfv[t];
                 double smoothbehavior = 1.0;
                 if (i >= md) smoothbehavior = pcf * beh[t];
@@ -956,33 +878,20 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                 }
                 ncur = nnext;
             }
-            if (LEAN || b == 0) {
+            if (b == 0) {
 #pragma unroll
                 for (int q = 0; q < T; ++q) {
                     WA[q] = hbase[q * MCMC_WAVE + lane];
                     WB[q] = hbase[(q + T) * MCMC_WAVE + lane];
                 }
             }
-            if constexpr (COOP) {             /* publish the block: history rows, correction range */
-                ps->w[2] = keLo;
-                ps->w[3] = keHi;
-                pair_signal(*ps, 0, fbase + b + 1);
-            }
             pc.stamp(PH_DAYS);
         }
-        if constexpr (COOP) {
-            /* the likelihood pass is role 0's, once every block of the pass is published */
-            if (ps->role != 0) continue;
-            const int nb = (horizon - ws + T - 1) / T;
-            if (nb > 0) pair_wait(*ps, 0, fbase + nb);
-            pc.stamp(PH_WAIT);
-        }
-
         /* log-likelihood of this pass (covid.h:488-492), data days in order: the output
          * coord `dead` is the first pass's weighted deaths (multset, covid.h:475), plus this
          * pass's in the second (multadd, covid.h:484).  A streaming loop over two per-lane
-         * rows and the LDS-resident observations.  (SPLIT: done by loglike_passes().) */
-        if constexpr (!SPLIT) {
+         * rows and the LDS-resident observations. */
+        {
             /* eight data days per trip: all loads of a trip are requested before the first
              * term is formed, so one memory round trip is paid per eight days, not per day */
             const double* d1_u = B.d1s_u;
@@ -1011,46 +920,6 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
             }
         }
         pc.stamp(PH_LOGLIKE);
-    }
-    return loglike;
-}
-
-/* The likelihood sums of both passes (covid.h:488-492) once their weighted deaths are in d1s --
- * the same terms in the same order as the two blocks at the end of eval_model's shift loop
- * (first the shift = 1 pass, then shift = 0 over the sum of both).  Used by the SPLIT kernel,
- * where each pass runs in a wave of its own. */
-__device__ __forceinline__ double loglike_passes(const DevModel& M, const LdsView& lds, const WaveBases& B,
-                                                 const LaneScalars& lp, unsigned lane) {
-    const int start = (int)((double)M.md - lp.delay);               /* covid.h:331, unclamped as in eval_model */
-    const double frac = (double)M.md - lp.delay - (double)start;    /* covid.h:332 */
-    double loglike = 0;
-    const double* d1_u = B.d1s_u;
-    const double* d0_u = B.d1s_u + M.nData * MCMC_WAVE;
-    constexpr int LB = MCMC_LL_BATCH;
-#pragma unroll 1
-    for (int shift = 1; shift >= 0; --shift) {
-        const double w = (double)(1 - shift) * (1.0 - frac) + (double)shift * frac;
-#pragma unroll 1
-        for (int d0 = 0; d0 < M.nData; d0 += LB) {
-            double dv[LB];
-#pragma unroll
-            for (int j = 0; j < LB; ++j) dv[j] = d1_u[min(d0 + j, M.nData - 1) * MCMC_WAVE + lane];
-            if (shift == 0) {
-                double d2[LB];
-#pragma unroll
-                for (int j = 0; j < LB; ++j) d2[j] = d0_u[min(d0 + j, M.nData - 1) * MCMC_WAVE + lane];
-#pragma unroll
-                for (int j = 0; j < LB; ++j) dv[j] = dv[j] + d2[j];
-            }
-#pragma unroll
-            for (int j = 0; j < LB; ++j) {
-                const int di = d0 + j;
-                if (di < M.nData) {
-                    const double delta = dv[j] - lds.deaths[di];
-                    loglike += w * (-0.5 * delta * delta / lds.sigma2[di]);
-                }
-            }
-        }
     }
     return loglike;
 }
@@ -1230,7 +1099,7 @@ struct ChainState {
     double* stepsize;             /* [nTiles][64]                                        */
     uint64_t* rng;                /* [nTiles][2][64]: state, inc                         */
     int* nAccept;                 /* [nTiles][64]                                        */
-    unsigned long long* pairs;    /* [nTiles][64]                                        */
+    unsigned long long* pairs;    /* [nTiles][2][64]: WorkCount algo, exec               */
     double* hn; double* he;       /* [nTiles][histRows][64]                              */
     double* d1s;                  /* [nTiles][2*nData][64]                               */
     double* mean;                 /* [nTiles][dim][64] or null                           */
@@ -1296,7 +1165,10 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
     double llModel = ll_u[lane], llPrior = ll_u[MCMC_WAVE + lane];
     double stepsize = S.stepsize[flat];
     int nAccept = S.nAccept[flat];
-    unsigned long long pairs = S.pairs[flat];
+    unsigned long long* pairs_u = S.pairs + (size_t)tile * 2 * MCMC_WAVE;
+    WorkCount work;
+    work.algo = pairs_u[lane];
+    work.exec = pairs_u[MCMC_WAVE + lane];
     const WaveBases B = wave_bases(M, S, tile, xp_u);
     int slot = slot0;
     PhaseClock pc;
@@ -1341,8 +1213,8 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
         const bool behChanged = propose(M, rnd, xc_u, xp_u, lane, stepsize, lp, llpNew);
         pc.stamp(PH_PROPOSE);
         double llm;
-        if constexpr (PREC == 1) llm = eval_model_f32<MCMC_TF>(M, lds, B, lp, lane, pairs, pc);   /* fast mode */
-        else llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, pairs, pc);
+        if constexpr (PREC == 1) llm = eval_model_f32<MCMC_TF>(M, lds, B, lp, lane, work, pc);   /* fast mode */
+        else llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, work, pc);
         double llp = 0.0;
         double delta = 0;                                           /* mcmc.h:604-606 */
         delta += -llModel + llm;
@@ -1385,298 +1257,8 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
     ll_u[MCMC_WAVE + lane] = llPrior;
     S.stepsize[flat] = stepsize;
     S.nAccept[flat] = nAccept;
-    S.pairs[flat] = pairs;
-}
-
-/* The same MH steps with a cooperative pair of waves per tile (see "cooperative pair"):
- * workgroups of 8 waves = 4 tiles, role = wave & 1.  Results are bit-identical to
- * mh_step_kernel: the arithmetic of a chain and its order do not change, only which wave
- * executes it. */
-#define MCMC_COOP_BLOCK (2 * MCMC_BLOCK)
-#define MCMC_COOP_SYNC_BYTES 128
-__host__ __device__ inline size_t coop_sync_offset(const DevModel& M, int T) {
-    return (lds_bytes(M, false, T) + 15) & ~(size_t)15;
-}
-template <int T, bool FUSE>
-__global__ __launch_bounds__(MCMC_COOP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void mh_step_coop_kernel(DevModel M, ChainState S, int n_steps, const double* __restrict__ betas,
-                         const int* __restrict__ flags, int slot0, int* __restrict__ err) {
-    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
-    int* syncWords = (int*)((char*)lds_raw + coop_sync_offset(M, T));
-    if (threadIdx.x < MCMC_COOP_SYNC_BYTES / 4) syncWords[threadIdx.x] = 0;
-    const LdsView lds = stage_lds(M, lds_raw, false, T);            /* ends with the workgroup barrier */
-    const unsigned lane = threadIdx.x & (MCMC_WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / MCMC_WAVE));
-    /* waves w and w+4 of a workgroup share a SIMD: they are one pair, so that the SIMD has
-     * the eval work of both roles and role 0's per-step work alone */
-    const int pairIdx = wave & (MCMC_WAVES_PER_BLOCK - 1);
-    const int tile = (int)blockIdx.x * MCMC_WAVES_PER_BLOCK + pairIdx;
-    if (tile >= S.nTiles) return;
-    PairSync ps;
-    ps.w = (volatile int*)(syncWords + pairIdx * 8);
-    ps.role = wave / MCMC_WAVES_PER_BLOCK;
-    ps.err = err;
-    int passCounter = 0;
-    const size_t tileVec = (size_t)S.dim * MCMC_WAVE;
-    const double* xc_u = S.params + (size_t)tile * tileVec;
-    double* xcw_u = S.params + (size_t)tile * tileVec;
-    double* xp_u = S.prop + (size_t)tile * tileVec;
-    uint64_t* rng_u = S.rng + (size_t)tile * 2 * MCMC_WAVE;
-    double* ll_u = S.ll + (size_t)tile * 2 * MCMC_WAVE;
-    const size_t flat = (size_t)tile * MCMC_WAVE + lane;
-    const WaveBases B = wave_bases(M, S, tile, xp_u);
-    PhaseClock pc;
-    pc.start();
-    unsigned long long pairs = 0;
-
-    if (ps.role == 1) {                       /* the helper: its half of every model evaluation */
-#pragma unroll 1
-        for (int g = 0; g < n_steps; ++g) {
-            pair_wait(ps, 1, g + 1);                                /* proposal g is in xp_u */
-            pc.stamp(PH_WAIT);
-            LaneScalars lp;
-            load_lane_scalars(M, xp_u, lane, lp);
-            (void)eval_model<T, FUSE, false, true>(M, lds, B, lp, lane, pairs, pc, &ps, &passCounter);
-        }
-        pc.flush(lane);
-        return;
-    }
-
-    Pcg32 rnd;
-    rnd.state = rng_u[lane];
-    rnd.inc = rng_u[MCMC_WAVE + lane];
-    double llModel = ll_u[lane], llPrior = ll_u[MCMC_WAVE + lane];
-    double stepsize = S.stepsize[flat];
-    int nAccept = S.nAccept[flat];
-    pairs = S.pairs[flat];
-    int slot = slot0;
-    const double rungBeta = S.chainBeta ? S.chainBeta[flat] : 1.0;
-
-#pragma unroll 1
-    for (int g = 0; g < n_steps; ++g) {
-        const int fl = flags[g];
-        const double beta = betas[g] * rungBeta;
-        if (fl & SF_RESET_ACC) nAccept = 0;
-        if (fl & SF_RECORD) {
-            double l = 0;
-            l += llModel;
-            if (M.hasPrior) l += llPrior;
-            S.recLL[((size_t)slot * S.nTiles + tile) * MCMC_WAVE + lane] = 0.0 + beta * l;
-            if (S.recSamples) {
-                double* dst = S.recSamples + ((size_t)slot * S.nTiles + tile) * tileVec;
-                for (int k = 0; k < S.dim; ++k) dst[k * MCMC_WAVE + lane] = xc_u[k * MCMC_WAVE + lane];
-            }
-            ++slot;
-        }
-        if ((fl & SF_MEAN) && S.mean) {
-            double* mu = S.mean + (size_t)tile * tileVec;
-            for (int k = 0; k < S.dim; ++k) mu[k * MCMC_WAVE + lane] += xc_u[k * MCMC_WAVE + lane];
-        }
-        if (fl & SF_RANDOM) {
-            const int nState = M.hasPrior ? 2 : 1;
-            int head;
-            do {
-                const float f = rnd.next_float() * (float)nState;
-                head = min((int)f, nState - 1);
-            } while (head != 0);
-        }
-        pc.stamp(PH_RECORD);
-        LaneScalars lp;
-        double llpNew;
-        const bool behChanged = propose(M, rnd, xc_u, xp_u, lane, stepsize, lp, llpNew);
-        pair_signal(ps, 1, g + 1);
-        pc.stamp(PH_PROPOSE);
-        const double llm = eval_model<T, FUSE, false, true>(M, lds, B, lp, lane, pairs, pc, &ps, &passCounter);
-        double llp = 0.0;
-        double delta = 0;
-        delta += -llModel + llm;
-        if (M.hasPrior) {
-            llp = behChanged ? llpNew : llPrior;
-            delta += -llPrior + llp;
-        }
-        delta += 0.0;
-        delta *= beta;
-        const double u = (double)rnd.next_float();
-        const bool accept = u < 1.0 * mcmc_exp(delta);
-        if (__any(accept)) {
-            constexpr int AB = MCMC_ACC_BATCH;
-#pragma unroll 1
-            for (int k0 = 0; k0 < S.dim; k0 += AB) {
-                double vv[AB];
-#pragma unroll
-                for (int j = 0; j < AB; ++j) vv[j] = xp_u[min(k0 + j, S.dim - 1) * MCMC_WAVE + lane];
-#pragma unroll
-                for (int j = 0; j < AB; ++j)
-                    if (accept && k0 + j < S.dim) xcw_u[(k0 + j) * MCMC_WAVE + lane] = vv[j];
-            }
-        }
-        if (accept) {
-            llModel = llm;
-            llPrior = llp;
-            ++nAccept;
-        }
-        if (fl & SF_ADJUST_END) {
-            const double acceptRate = (double)nAccept / 20;
-            stepsize *= rate2corr(acceptRate);
-        }
-        pc.stamp(PH_ACCEPT);
-    }
-    pc.flush(lane);
-    rng_u[lane] = rnd.state;
-    ll_u[lane] = llModel;
-    ll_u[MCMC_WAVE + lane] = llPrior;
-    S.stepsize[flat] = stepsize;
-    S.nAccept[flat] = nAccept;
-    S.pairs[flat] = pairs;
-}
-
-/* The same MH steps with the two PASSES of a model evaluation (covid.h:335: the two integer
- * day shifts that are blended for the fractional delay) in two waves of one SIMD.  The passes
- * are independent forward simulations; they meet only in the likelihood sums.  Workgroups of 8
- * waves = 4 tiles; waves w and w+4 share a SIMD and a tile: the main wave (role 0) proposes,
- * runs the shift = 0 pass, waits for its partner, sums the likelihood of both passes and
- * accepts; the partner (role 1) runs the shift = 1 pass on a history set of its own
- * (S.hn / S.he hold 2*nTiles tiles here).  Two hand-overs per step through two monotone LDS
- * words: [1] proposals published, [0] shift-1 passes finished.  The partner's weighted deaths
- * travel through global memory; both waves share the CU's vector L1, and a release/acquire pair
- * at workgroup scope orders them (as in the COOP kernel).  Arithmetic and its order per chain
- * are those of mh_step_kernel: results are bit-identical. */
-template <int T, bool FUSE>
-__global__ __launch_bounds__(MCMC_COOP_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void mh_step_split_kernel(DevModel M, ChainState S, int n_steps, const double* __restrict__ betas,
-                          const int* __restrict__ flags, int slot0, int* __restrict__ err) {
-    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
-    int* syncWords = (int*)((char*)lds_raw + coop_sync_offset(M, T));
-    if (threadIdx.x < MCMC_COOP_SYNC_BYTES / 4) syncWords[threadIdx.x] = 0;
-    const LdsView lds = stage_lds(M, lds_raw, false, T);            /* ends with the workgroup barrier */
-    const unsigned lane = threadIdx.x & (MCMC_WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / MCMC_WAVE));
-    const int pairIdx = wave & (MCMC_WAVES_PER_BLOCK - 1);
-    const int tile = (int)blockIdx.x * MCMC_WAVES_PER_BLOCK + pairIdx;
-    if (tile >= S.nTiles) return;
-    PairSync ps;
-    ps.w = (volatile int*)(syncWords + pairIdx * 8);
-    ps.role = wave / MCMC_WAVES_PER_BLOCK;
-    ps.err = err;
-    const size_t tileVec = (size_t)S.dim * MCMC_WAVE;
-    const double* xc_u = S.params + (size_t)tile * tileVec;
-    double* xcw_u = S.params + (size_t)tile * tileVec;
-    double* xp_u = S.prop + (size_t)tile * tileVec;
-    uint64_t* rng_u = S.rng + (size_t)tile * 2 * MCMC_WAVE;
-    double* ll_u = S.ll + (size_t)tile * 2 * MCMC_WAVE;
-    const size_t flat = (size_t)tile * MCMC_WAVE + lane;
-    WaveBases B = wave_bases(M, S, tile, xp_u);
-    PhaseClock pc;
-    pc.start();
-    unsigned long long pairs = 0;
-
-    if (ps.role == 1) {                       /* the partner: the shift = 1 pass of every evaluation */
-        /* its own history set: tiles [nTiles, 2*nTiles) of S.hn / S.he */
-        B.hn_u = S.hn + ((size_t)S.nTiles + tile) * S.histRows * MCMC_WAVE;
-        B.he_u = S.he + ((size_t)S.nTiles + tile) * S.histRows * MCMC_WAVE;
-#pragma unroll 1
-        for (int g = 0; g < n_steps; ++g) {
-            pair_wait(ps, 1, g + 1);                                /* proposal g is in xp_u */
-            pc.stamp(PH_WAIT);
-            LaneScalars lp;
-            load_lane_scalars(M, xp_u, lane, lp);
-            (void)eval_model<T, FUSE, false, false, true>(M, lds, B, lp, lane, pairs, pc, nullptr, nullptr, 1);
-            pair_signal(ps, 0, g + 1);                              /* its weighted deaths are in d1s */
-        }
-        pc.flush(lane);
-        return;
-    }
-
-    Pcg32 rnd;
-    rnd.state = rng_u[lane];
-    rnd.inc = rng_u[MCMC_WAVE + lane];
-    double llModel = ll_u[lane], llPrior = ll_u[MCMC_WAVE + lane];
-    double stepsize = S.stepsize[flat];
-    int nAccept = S.nAccept[flat];
-    pairs = S.pairs[flat];
-    int slot = slot0;
-    const double rungBeta = S.chainBeta ? S.chainBeta[flat] : 1.0;
-
-#pragma unroll 1
-    for (int g = 0; g < n_steps; ++g) {
-        const int fl = flags[g];
-        const double beta = betas[g] * rungBeta;
-        if (fl & SF_RESET_ACC) nAccept = 0;
-        if (fl & SF_RECORD) {
-            double l = 0;
-            l += llModel;
-            if (M.hasPrior) l += llPrior;
-            S.recLL[((size_t)slot * S.nTiles + tile) * MCMC_WAVE + lane] = 0.0 + beta * l;
-            if (S.recSamples) {
-                double* dst = S.recSamples + ((size_t)slot * S.nTiles + tile) * tileVec;
-                for (int k = 0; k < S.dim; ++k) dst[k * MCMC_WAVE + lane] = xc_u[k * MCMC_WAVE + lane];
-            }
-            ++slot;
-        }
-        if ((fl & SF_MEAN) && S.mean) {
-            double* mu = S.mean + (size_t)tile * tileVec;
-            for (int k = 0; k < S.dim; ++k) mu[k * MCMC_WAVE + lane] += xc_u[k * MCMC_WAVE + lane];
-        }
-        if (fl & SF_RANDOM) {
-            const int nState = M.hasPrior ? 2 : 1;
-            int head;
-            do {
-                const float f = rnd.next_float() * (float)nState;
-                head = min((int)f, nState - 1);
-            } while (head != 0);
-        }
-        pc.stamp(PH_RECORD);
-        LaneScalars lp;
-        double llpNew;
-        const bool behChanged = propose(M, rnd, xc_u, xp_u, lane, stepsize, lp, llpNew);
-        pair_signal(ps, 1, g + 1);
-        pc.stamp(PH_PROPOSE);
-        (void)eval_model<T, FUSE, false, false, true>(M, lds, B, lp, lane, pairs, pc, nullptr, nullptr, 0);
-        pair_wait(ps, 0, g + 1);                                    /* the partner's pass is in d1s */
-        pc.stamp(PH_WAIT);
-        const double llm = loglike_passes(M, lds, B, lp, lane);
-        pc.stamp(PH_LOGLIKE);
-        double llp = 0.0;
-        double delta = 0;
-        delta += -llModel + llm;
-        if (M.hasPrior) {
-            llp = behChanged ? llpNew : llPrior;
-            delta += -llPrior + llp;
-        }
-        delta += 0.0;
-        delta *= beta;
-        const double u = (double)rnd.next_float();
-        const bool accept = u < 1.0 * mcmc_exp(delta);
-        if (__any(accept)) {
-            constexpr int AB = MCMC_ACC_BATCH;
-#pragma unroll 1
-            for (int k0 = 0; k0 < S.dim; k0 += AB) {
-                double vv[AB];
-#pragma unroll
-                for (int j = 0; j < AB; ++j) vv[j] = xp_u[min(k0 + j, S.dim - 1) * MCMC_WAVE + lane];
-#pragma unroll
-                for (int j = 0; j < AB; ++j)
-                    if (accept && k0 + j < S.dim) xcw_u[(k0 + j) * MCMC_WAVE + lane] = vv[j];
-            }
-        }
-        if (accept) {
-            llModel = llm;
-            llPrior = llp;
-            ++nAccept;
-        }
-        if (fl & SF_ADJUST_END) {
-            const double acceptRate = (double)nAccept / 20;
-            stepsize *= rate2corr(acceptRate);
-        }
-        pc.stamp(PH_ACCEPT);
-    }
-    pc.flush(lane);
-    rng_u[lane] = rnd.state;
-    ll_u[lane] = llModel;
-    ll_u[MCMC_WAVE + lane] = llPrior;
-    S.stepsize[flat] = stepsize;
-    S.nAccept[flat] = nAccept;
-    S.pairs[flat] = pairs;
+    pairs_u[lane] = work.algo;
+    pairs_u[MCMC_WAVE + lane] = work.exec;
 }
 
 /* State::eval (mcmc.h:385-393) of parameter vectors laid out [nTiles][dim][64]:
@@ -1691,12 +1273,12 @@ __global__ MCMC_KERNEL_ATTRS void eval_kernel(DevModel M, ChainState S, const do
     const WaveBases B = wave_bases(M, S, tile, x + (size_t)tile * S.dim * MCMC_WAVE);
     LaneScalars lp;
     load_lane_scalars(M, B.x_u, lane, lp);
-    unsigned long long pairs = 0;
+    WorkCount work = {0, 0};
     PhaseClock pc;
     pc.start();
     double llm;
-    if constexpr (PREC == 1) llm = eval_model_f32<MCMC_TF>(M, lds, B, lp, lane, pairs, pc);
-    else llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, pairs, pc);
+    if constexpr (PREC == 1) llm = eval_model_f32<MCMC_TF>(M, lds, B, lp, lane, work, pc);
+    else llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, work, pc);
     const double llp = M.hasPrior ? eval_prior(M, B.x_u, lane) : 0.0;
     llOut[((size_t)tile * 2) * MCMC_WAVE + lane] = llm;
     llOut[((size_t)tile * 2 + 1) * MCMC_WAVE + lane] = llp;
@@ -1715,10 +1297,10 @@ __global__ MCMC_KERNEL_ATTRS void derive_kernel(DevModel M, ChainState S, const 
     B.curves_u = curves + (size_t)tile * 9 * M.size * MCMC_WAVE;
     LaneScalars lp;
     load_lane_scalars(M, B.x_u, lane, lp);
-    unsigned long long pairs = 0;
+    WorkCount work = {0, 0};
     PhaseClock pc;
     pc.start();
-    (void)eval_model<T, FUSE, true>(M, lds, B, lp, lane, pairs, pc);
+    (void)eval_model<T, FUSE, true>(M, lds, B, lp, lane, work, pc);
 }
 
 /* [n][rows] chain-major (host layout) <-> [nTiles][rows][64] tiles; pad lanes of the last

@@ -179,7 +179,7 @@ __device__ __forceinline__ void lag_tail_f(float2_t (&acc)[P_N][T], const float 
  */
 template <int T>
 __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsView& lds, const WaveBases& B,
-                                                 const LaneScalars& lp, unsigned lane, unsigned long long& pairs,
+                                                 const LaneScalars& lp, unsigned lane, WorkCount& work,
                                                  PhaseClock& pc) {
     const int md = M.md;
     const int horizon = M.simDays;
@@ -195,10 +195,7 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
     int start = (int)((double)md - lp.delay);                       /* covid.h:331 */
     const double frac = (double)md - lp.delay - (double)start;      /* covid.h:332 */
     start = min(max(start, 0), horizon);                            /* memory safety, as in eval_model */
-    {
-        long long m1 = M.size - min(start + 1, M.size), m0 = M.size - min(start, M.size);
-        pairs += (unsigned long long)(m1 * (m1 + 1) / 2 + m0 * (m0 + 1) / 2);
-    }
+    count_work(M, start, work);
 
 #pragma unroll 1
     for (int shift = 1; shift >= 0; --shift) {                      /* covid.h:335 */

@@ -28,6 +28,7 @@ SYMBOLS = [
     "mcmc_hip_get_accept_counts", "mcmc_hip_get_rng_state", "mcmc_hip_get_loglikes",
     "mcmc_hip_get_samples", "mcmc_hip_get_sample_all", "mcmc_hip_get_mean", "mcmc_hip_eval",
     "mcmc_hip_derive", "mcmc_hip_diagnostics", "mcmc_hip_last_timing", "mcmc_hip_pair_count",
+    "mcmc_hip_executed_pair_count",
     "mcmc_hip_debug_phase_cycles", "mcmc_hip_set_ladder", "mcmc_hip_swap", "mcmc_hip_run_tempered",
     "mcmc_hip_get_rungs", "mcmc_hip_get_swap_counts", "mcmc_hip_toy_dim", "mcmc_hip_toy_n_out", "mcmc_hip_toy_eval", "mcmc_hip_toy_run",
 ]
@@ -98,6 +99,7 @@ def lib():
     L.mcmc_hip_derive.argtypes = [vp, C.c_int64, dp, dp]
     L.mcmc_hip_last_timing.argtypes = [vp, dp, dp, dp, C.POINTER(C.c_int64)]
     L.mcmc_hip_pair_count.argtypes = [vp, dp, C.c_int32]
+    L.mcmc_hip_executed_pair_count.argtypes = [vp, dp, C.c_int32]
     L.mcmc_hip_debug_phase_cycles.argtypes = [vp, dp, C.c_int32]
     L.mcmc_hip_set_ladder.argtypes = [vp, C.c_int32, dp, C.c_uint64, C.c_uint64]
     L.mcmc_hip_swap.argtypes = [vp, C.c_int32]
@@ -342,4 +344,9 @@ class CovidSampler:
     def pair_count(self, reset=False):
         v = C.c_double()
         _check(lib().mcmc_hip_pair_count(self._h, C.byref(v), int(reset)))
+        return v.value
+
+    def executed_pair_count(self, reset=False):
+        v = C.c_double()
+        _check(lib().mcmc_hip_executed_pair_count(self._h, C.byref(v), int(reset)))
         return v.value

@@ -449,11 +449,15 @@ void orc_chain_init(const orc_covid_model* m, orc_chain* c, int chain_id, const 
     c->xp = (double*)malloc(sizeof(double) * dim);
     memcpy(c->x, x0, sizeof(double) * dim);
     c->stepsize = stepsize;
+    if (m->faithful && m->grid) {                                   /* traj held by value, covid.h:290 */
+        c->grid_own = (double*)malloc(sizeof(double) * ORC_NCURVES * ORC_NGRID);
+        memcpy(c->grid_own, m->grid, sizeof(double) * ORC_NCURVES * ORC_NGRID);
+    }
     /* State::init/eval (mcmc.h:385-393): deterministic, so one sweep equals ten */
     c->ll_model = orc_covid_eval(m, c->x, NULL, 0);
     c->ll_prior = m->has_prior ? orc_smooth_eval(c->x, orc_nb(m), m->smooth_Ls, m->smooth_L) : 0.0;
 }
-void orc_chain_free(orc_chain* c) { free(c->x); free(c->xp); c->x = c->xp = NULL; }
+void orc_chain_free(orc_chain* c) { free(c->x); free(c->xp); free(c->grid_own); c->x = c->xp = c->grid_own = NULL; }
 
 /* Target::step (mcmc.h:750-783) on State=[DiseaseSpread(,SmoothnessPrior)] */
 int orc_chain_step(const orc_covid_model* m, const orc_target* t, orc_chain* c, double time,
@@ -470,7 +474,19 @@ int orc_chain_step(const orc_covid_model* m, const orc_target* t, orc_chain* c, 
     }
     /* head is always 0 (given-subspace steps reuse rec.whichHead of the same iteration) */
     orc_covid_propose(m, &c->rng, c->x, c->stepsize, c->xp);        /* mcmc.h:513 */
-    double llm = orc_covid_eval(m, c->xp, NULL, 0);                 /* covid.h:624 */
+    /* faithful: the proposal is a copy() of the whole DiseaseSpread (covid.h:501, HAS_STEP
+     * mcmc.h:55-56), trajectory arrays included: 11 fresh vectors of nGrid doubles, which the
+     * proposal's eval then reads; the loser of the accept test is freed */
+    orc_covid_model mm;
+    const orc_covid_model* me = m;
+    double* grid_prop = NULL;
+    if (c->grid_own) {
+        grid_prop = (double*)malloc(sizeof(double) * ORC_NCURVES * ORC_NGRID);
+        for (int cv = 0; cv < ORC_NCURVES; ++cv)
+            memcpy(grid_prop + (size_t)cv * ORC_NGRID, c->grid_own + (size_t)cv * ORC_NGRID, sizeof(double) * ORC_NGRID);
+        mm = *m; mm.grid = grid_prop; me = &mm;
+    }
+    double llm = orc_covid_eval(me, c->xp, NULL, 0);                /* covid.h:624 */
     double llp = 0.0;
     double delta = 0;                                               /* mcmc.h:604-606 */
     delta += -c->ll_model + llm;
@@ -489,7 +505,9 @@ int orc_chain_step(const orc_covid_model* m, const orc_target* t, orc_chain* c, 
         c->ll_prior = llp;
         c->n_accept++;
         acc = 1;
+        if (grid_prop) { double* g = c->grid_own; c->grid_own = grid_prop; grid_prop = g; }
     }
+    free(grid_prop);
     c->last_accept = acc;
     return acc;
 }

@@ -105,7 +105,10 @@ typedef struct {
                                    use fma() as gcc -ffp-contract=fast would       */
     int use_libm;               /* 0: mcmc_detmath cos/exp; 1: libm cos/exp       */
     int faithful;               /* 1: recompute cumsum from grid via getDay per project()
-                                   call like covid.h:376-386 (slow; CPU "faithful" leg) */
+                                   call like covid.h:376-386, AND give every proposal a fresh
+                                   copy of the 8.8 MB trajectory arrays, as copy() at covid.h:501
+                                   does through `AvgDiseaseTrajectory traj` held by value
+                                   (covid.h:290); slow -- the CPU "faithful" leg of bench.py */
 } orc_covid_model;
 
 static inline int orc_size(const orc_covid_model* m) { return m->max_delay + m->n_predict + m->n_data; }
@@ -145,6 +148,8 @@ typedef struct {
     uint64_t n_steps;   /* Target::step calls so far                              */
     double last_delta;  /* rec.deltaloglike of the last step (after *beta)        */
     int    last_accept;
+    double* grid_own;   /* faithful=1: this chain's own copy of the 11 x nGrid trajectory arrays
+                           (DiseaseSpread holds AvgDiseaseTrajectory BY VALUE, covid.h:290)  */
 } orc_chain;
 
 void orc_chain_init(const orc_covid_model* m, orc_chain* c, int chain_id,

@@ -63,7 +63,7 @@ class Chain(C.Structure):
     _fields_ = [("rng", Pcg32), ("x", C.POINTER(C.c_double)), ("xp", C.POINTER(C.c_double)),
                 ("ll_model", C.c_double), ("ll_prior", C.c_double), ("stepsize", C.c_double),
                 ("n_accept", C.c_int), ("n_steps", C.c_uint64), ("last_delta", C.c_double),
-                ("last_accept", C.c_int)]
+                ("last_accept", C.c_int), ("grid_own", C.POINTER(C.c_double))]
 
 
 _lib = None

@@ -503,6 +503,13 @@ def test_pair_count_is_the_survey_work_unit(R11, R10):
     size = cfg["size"]
     lo = 64 * sum((size - 5 - k) * (size - 5 - k + 1) // 2 for k in (0, 1))
     assert abs(got - lo) <= 64 * 4 * size          # a changed delay moves start by at most +-1
+    # the executed count: the same sum over the days the log-likelihood can see (maxDelay + nData)
+    sim = cfg["max_delay"] + cfg["n_data"]
+    ex = 64 * sum((sim - 5 - k) * (sim - 5 - k + 1) // 2 for k in (0, 1))
+    assert abs(s.executed_pair_count() - ex) <= 64 * 4 * sim
+    assert s.executed_pair_count() < got
+    s.executed_pair_count(reset=True)
+    assert s.pair_count() == 0 and s.executed_pair_count() == 0
     s.close()
 
 

@@ -175,3 +175,38 @@ def test_bench_fails_loudly_without_a_gpu():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "no GPU visible" in (r.stderr + r.stdout)
     assert "{" not in r.stdout                       # and prints no result line
+
+
+def test_bench_gpus_flag_plans_one_rank_per_gpu():
+    """`bench.py --gpus N`: a plain call with N > 1 becomes N rank processes (ranks 0..N-1, one
+    rendezvous on 127.0.0.1); a process that already is a rank, or N = 1, runs the benchmark itself.
+    Decided before anything touches the GPU (no GPU is touched here either)."""
+    from mcmc_amd import launcher as LA
+    assert LA.plan_launch(1, {}) is None
+    assert LA.plan_launch(4, {"WORLD_SIZE": "4", "RANK": "2"}) is None          # under torch.distributed.run
+    with pytest.raises(ValueError):
+        LA.plan_launch(8, {"WORLD_SIZE": "2"})
+    with pytest.raises(ValueError):
+        LA.plan_launch(0, {})
+    ov = LA.plan_launch(8, {})
+    assert [o["RANK"] for o in ov] == [str(r) for r in range(8)]
+    assert [o["LOCAL_RANK"] for o in ov] == [str(r) for r in range(8)]
+    assert {o["WORLD_SIZE"] for o in ov} == {"8"} and {o["MASTER_ADDR"] for o in ov} == {"127.0.0.1"}
+    assert len({o["MASTER_PORT"] for o in ov}) == 1 and {o["HSA_ENABLE_IPC_MODE_LEGACY"] for o in ov} == {"0"}
+
+
+def test_bench_gpus_flag_spawns_the_ranks_and_reports_failure(tmp_path):
+    """spawn_ranks starts one interpreter per overlay with the rank environment and returns the
+    first failing exit code; bench.py --gpus 2 without a GPU fails in its ranks, loudly."""
+    from mcmc_amd import launcher as LA
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys\nopen(sys.argv[1] + os.environ['RANK'], 'w').write(os.environ['WORLD_SIZE'])\n"
+                      "sys.exit(3 if os.environ['RANK'] == '1' and len(sys.argv) > 2 else 0)\n")
+    ov = LA.plan_launch(2, {})
+    assert LA.spawn_ranks(str(script), [str(tmp_path / "r")], ov) == 0
+    assert (tmp_path / "r0").read_text() == "2" and (tmp_path / "r1").read_text() == "2"
+    assert LA.spawn_ranks(str(script), [str(tmp_path / "q"), "fail"], ov) == 3
+    if H.lib().mcmc_hip_device_count() == 0:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "no GPU visible" in (r.stderr + r.stdout) and "{" not in r.stdout

@@ -329,3 +329,168 @@ def test_reference_notebook_outputs():
     pick0 = int(np.searchsorted(cdf, r.next_double() * total, side="right"))
     _, st, _, _ = O.fourgauss_run(6.0, 1.0, 1, cand[pick0], 100, 0, 0, 1)
     assert np.allclose(st[[10 * k + 1 for k in range(1, 10)]], g["cell8"]["chain0_pos"], rtol=0, atol=tol)
+
+
+# ---------------------------------------------------------------------------------------
+# An independent restatement of DiseaseSpread::step up to its eval call (covid.h:499-622),
+# written from the reference text in plain Python: own pcg32 on Python integers, float32 gates
+# through numpy.float32, C's round() spelled out, libm cos.  Checked draw for draw against
+# orc_covid_propose (run with use_libm=1, since the reference calls std::cos).
+class PyPcg32:
+    MULT = 0x5851f42d4c957f2d
+    M64 = (1 << 64) - 1
+
+    def __init__(self, initstate, initseq):            # pcg32::seed
+        self.state, self.inc = 0, ((initseq << 1) | 1) & self.M64
+        self.next_uint()
+        self.state = (self.state + initstate) & self.M64
+        self.next_uint()
+
+    def next_uint(self):
+        old = self.state
+        self.state = (old * self.MULT + self.inc) & self.M64
+        xorshifted = (((old >> 18) ^ old) >> 27) & 0xffffffff
+        rot = old >> 59
+        return ((xorshifted >> rot) | (xorshifted << ((-rot) & 31))) & 0xffffffff
+
+    def next_float(self):                               # [0,1) float: mantissa trick, then - 1.0f
+        bits = np.array([(self.next_uint() >> 9) | 0x3f800000], dtype=np.uint32)
+        return np.float32(bits.view(np.float32)[0] - np.float32(1.0))
+
+    def next_double(self):
+        bits = np.array([(self.next_uint() << 20) | 0x3ff0000000000000], dtype=np.uint64)
+        return float(bits.view(np.float64)[0]) - 1.0
+
+
+def c_round(v):
+    """std::round: to nearest, halves away from zero (Python's round() goes to even)."""
+    a = abs(v)
+    f = math.floor(a)
+    return math.copysign(f + 1.0 if a - f >= 0.5 else f, v)
+
+
+def py_bound(val, lower, upper):                        # mcmc.h:49-53
+    val = 0.5 * (val - lower) / (upper - lower)
+    val = 2.0 * abs(val - c_round(val))
+    return lower + val * (upper - lower)
+
+
+def python_step_proposal(cfg, rnd, x, stepsize_fac):
+    """covid.h:499-622 on the coords vector [behavior | discontinuousVals | betaMild betaHigh delay]."""
+    nB, nDisc = cfg["nB"], cfg["n_disc"]
+    new = [float(v) for v in x]                         # newstate = copy()
+    i_bm, i_bh, i_delay = nB + nDisc, nB + nDisc + 1, nB + nDisc + 2
+    fixed = [bool(f) for f in cfg["disc_fixed"]]
+    sf = min(stepsize_fac, 1.0)
+    big = [rnd.next_float() < np.float32(0.6) for _ in range(5)]           # 503-507
+    if rnd.next_float() < np.float32(0.3):                                  # start time, 510-515
+        new[i_delay] += (rnd.next_double() - 0.5) * 0.5 * 0.1 * sf
+        if big[0]:
+            new[i_delay] += (rnd.next_double() - 0.5) * sf
+        new[i_delay] = py_bound(new[i_delay], 5.0, float(cfg["max_delay"]))
+    if rnd.next_float() < np.float32(0.3):                                  # betas, 518-532
+        if not big[1]:
+            new[i_bm] += (rnd.next_double() - 0.5) * 0.1 * sf
+        else:
+            new[i_bm] += (rnd.next_double() - 0.5) * sf
+        new[i_bm] = py_bound(new[i_bm], 0.0, 100.0)
+        if not big[2]:
+            new[i_bh] += (rnd.next_double() - 0.5) * 0.1 * sf
+        else:
+            new[i_bh] += (rnd.next_double() - 0.5) * sf
+        new[i_bh] = py_bound(new[i_bh], 0.0, 100.0)
+        if new[i_bh] < new[i_bm]:
+            new[i_bh], new[i_bm] = new[i_bm], new[i_bh]
+    if rnd.next_float() < np.float32(0.9):                                  # breakpoint values, 557-598
+        n_not_fixed = np.float32(0)
+        for i in range(nDisc):
+            if fixed[i]:                                                    # (sic) counts the fixed ones
+                n_not_fixed += np.float32(1)
+        order = list(range(nDisc))
+        if rnd.next_double() < 0.5:
+            order.reverse()                                                 # start = n-1, stop = -1, incr = -1
+        with np.errstate(divide="ignore"):
+            thr = np.float32(2) / n_not_fixed                               # int 2 / float -> float; inf if zero
+        for i in order:
+            if fixed[i]:
+                continue
+            xx = rnd.next_float()
+            if xx < thr:
+                if not big[3]:
+                    new[nB + i] += (rnd.next_double() - 0.5) * 0.1 * sf
+                else:
+                    new[nB + i] += (rnd.next_double() - 0.5) * sf
+                lower, upper = 0.0, 1.0
+                if i >= 1:
+                    upper = new[nB + i - 1]
+                if i < nDisc - 1:
+                    lower = new[nB + i + 1]
+                new[nB + i] = py_bound(new[nB + i], lower, upper)
+    if rnd.next_float() < np.float32(0.3):                                  # behaviour function, 601-622
+        T = float(cfg["n_data"])
+        xx = rnd.next_double()
+        omega = 2 * 3.1415 / T * 5 * xx * xx
+        A = min(1.0, stepsize_fac) * 0.1 * (rnd.next_double() - 0.5)
+        if big[4]:
+            A += min(1.0, stepsize_fac) * (rnd.next_double() - 0.5)
+        for i in range(nB):
+            new[i] += A * (math.cos(omega * i) - 1)
+            new[i] = py_bound(new[i], 0.0, 2.0)
+    return np.array(new)
+
+
+@pytest.mark.parametrize("variant", ["ipynb", "some_fixed", "all_fixed", "eight_breakpoints", "one_breakpoint"])
+def test_propose_matches_independent_python_restatement(R11, variant):
+    """orc_covid_propose against python_step_proposal, draw for draw: same proposal vector bit for
+    bit and the same generator state after every one of 400 proposals per chain (proposals are
+    chained: each starts from the previous proposal, as if every step were accepted), for step
+    size factors below and above 1."""
+    kw = dict(max_delay=12, n_predict=5, fix_behavior_in_advance=5, initial_delay=7.0)
+    if variant == "some_fixed":
+        kw.update(disc_fixed=[1, 0, 0, 1])
+    elif variant == "all_fixed":
+        kw.update(disc_fixed=[1, 1, 1, 1])
+    elif variant == "eight_breakpoints":
+        kw.update(disc_days=(1, 3, 5, 9, 12, 20, 25, 29), disc_vals=(1.0, 0.9, 0.8, 0.7, 0.6, 0.5, 0.45, 0.4),
+                  disc_fixed=[0, 0, 1, 0, 0, 0, 0, 0])
+    elif variant == "one_breakpoint":
+        kw.update(disc_days=(4,), disc_vals=(0.7,))
+    cfg = make_cfg(40, R11, **kw)
+    m = O.Model(cfg, R11, use_libm=1)
+    for chain_id, sfac in ((1, 1.0), (2, 0.37), (3, 2.5)):
+        x = perturbed(cfg, 1, 0.05, seq=chain_id)[0]
+        orng, prng = O.Rng(0, chain_id), PyPcg32(0, chain_id)
+        n_changed = 0
+        for it in range(400):
+            want = python_step_proposal(cfg, prng, x, sfac)
+            got = m.propose(orng, x, sfac)
+            assert np.array_equal(got, want), (variant, chain_id, it, np.nonzero(got != want))
+            assert orng.state == (prng.state, prng.inc), (variant, chain_id, it)
+            n_changed += int(not np.array_equal(got, x))
+            x = got
+        assert n_changed > 200
+
+
+def test_python_pcg32_reproduces_the_published_vector():
+    """the restatement's own generator against the PCG32 known-answer vector pcg32(42, 54)"""
+    r = PyPcg32(42, 54)
+    assert [r.next_uint() for _ in range(6)] == [0xa15c02b7, 0x7b47f409, 0xba1d3330, 0x83d2f293, 0xbfa4784b, 0xcbed606e]
+
+
+def test_faithful_copy_mode_runs_the_same_chain(R11):
+    """faithful=1 (a fresh copy of the trajectory arrays per proposal, running sums re-formed from
+    them: covid.h:290,501,376-386) only costs time: the chain is bit-identical to the lean one."""
+    p = O.DiseaseParams(**CC.ipynb_disease_params())
+    grid = O.traj_generate(p, 100_000)
+    R = O.traj_response(grid)
+    cfg = make_cfg(40, R, max_delay=12, n_predict=5, fix_behavior_in_advance=5, initial_delay=7.0)
+    lean, faithful = O.Model(cfg, R), O.Model(cfg, R, grid=grid, faithful=1)
+    tgt = O.make_target("temp", 1.0)
+    x0 = perturbed(cfg, 1, 0.05)[0]
+    a, b = O.OracleChain(lean, 1, x0), O.OracleChain(faithful, 1, x0)
+    for _ in range(25):
+        assert a.step(tgt) == b.step(tgt)
+    assert np.array_equal(a.x, b.x) and a.ll == b.ll and a.rng_state == b.rng_state
+    ra = O.run_chains(lean, tgt, perturbed(cfg, 3, 0.05), 1.0, 10, 0, 1, 1, n_threads=2)
+    rb = O.run_chains(faithful, tgt, perturbed(cfg, 3, 0.05), 1.0, 10, 0, 1, 1, n_threads=2)
+    assert np.array_equal(ra["x"], rb["x"]) and np.array_equal(ra["rng"], rb["rng"])
