@@ -132,6 +132,18 @@ int mcmc_hip_set_chains(mcmc_hip_ctx* ctx, int64_t n_chains, const double* param
                         const double* stepsizes, const uint64_t* chain_ids,
                         uint64_t first_chain_id);
 
+/* Continuing chains in another context or process (checkpoint / resume; the reference's own
+ * substitutes are the recorded `ics` + reevaluate(), mcmc.h:1141-1199, and seeding a manager from a
+ * finished chain, mcmc.h:1376-1418).  After set_chains (parameters, step sizes), this overrides
+ * what set_chains derives from scratch, each array chain-major as its getter returns it and each
+ * optional (NULL keeps set_chains' value): rng_state [n][2] = pcg32 (state, inc) of
+ * get_rng_state -- a MetropolisChain seeds `rnd` ONCE in its constructor and keeps drawing from it
+ * across run() calls (mcmc.h:994-999) --; loglike [n][2] of get_loglike; mean [n][dim] = the
+ * running `mean` a second run() keeps adding to (mcmc.h:1002,1064-1065,1133-1134; get_mean);
+ * accept_counts [n] = run()'s nAccept.  params + stepsizes + these four are a chain's whole state. */
+int mcmc_hip_set_state(mcmc_hip_ctx* ctx, const uint64_t* rng_state, const double* loglike,
+                       const double* mean, const int32_t* accept_counts);
+
 /* Replaces `chains[i].run(nSamples, nBurnin, nAdjust, thinning)` for ALL chains
  * (mcmc.h:1005-1138 under mcmc.h:1494-1508 / 1534-1548).  record_samples mirrors
  * MetropolisChain::recordSamples, compute_mean mirrors computeMean.  May be called again:
@@ -227,7 +239,11 @@ int mcmc_hip_get_swap_counts(mcmc_hip_ctx* ctx, int64_t* accepted, int64_t* prop
  * with the end state.  A saved point and the running mean (mcmc.h:1002,1064-1065,1133-1134)
  * hold ALL coords of the likelihood, n_out = dim + 1 for MyLike1 (its coordinate "max",
  * test.h:37) and dim for FourGaussians: loglikes_out [n][n_saved], samples_out
- * [n][n_saved][n_out], mean_out [n][n_out] and n_accept_out [n] may each be NULL. */
+ * [n][n_saved][n_out], mean_out [n][n_out] and n_accept_out [n] may each be NULL.
+ * A later run() of the same chains (the reference seeds `rnd` once per chain and keeps its `mean`,
+ * mcmc.h:994-1003): rng_state [n][2] non-NULL = start from these pcg32 (state, inc) instead of
+ * seeding, and receive the end state; mean_continue = 1: mean_out holds the previous run's mean
+ * on entry and the run adds to it (mcmc.h:1064-1065,1133-1134). */
 enum mcmc_toy_kind { MCMC_TOY_MYLIKE1 = 0, MCMC_TOY_FOURGAUSS = 1 };
 int mcmc_hip_toy_dim(int32_t kind);                                   /* 3, 2 */
 int mcmc_hip_toy_n_out(int32_t kind);                                 /* 4, 2 */
@@ -236,7 +252,8 @@ int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target
                      double target_slope, double target_Tinit, int64_t n_chains, const uint64_t* chain_ids,
                      uint64_t first_chain_id, double* x, double* stepsizes, int32_t n_samples,
                      int32_t n_burnin, int32_t n_adjust, int32_t thinning, double* loglikes_out,
-                     double* samples_out, double* mean_out, int32_t* n_accept_out);
+                     double* samples_out, double* mean_out, int32_t* n_accept_out,
+                     uint64_t* rng_state, int32_t mean_continue);
 
 /* Profiling aid: shader cycles summed over all waves per phase of the MH step since the last
  * reset, out[16] in the order propose, eval set-up, lag chunks, lag tail, day loop,

@@ -309,6 +309,20 @@ int run_schedule(mcmc_hip_ctx* c, const std::vector<double>& betas, const std::v
     return 0;
 }
 
+/* uploads a chain-major host field [n][rows] into a tile-major device field [nTiles][rows][64] */
+template <typename Tp>
+int upload_field(mcmc_hip_ctx* c, const Tp* host, int rows, Tp* dev) {
+    const long long n = c->nChains, nP = c->nP;
+    DevBuf<Tp> stage;
+    if (int r = stage.alloc((size_t)n * rows)) return r;
+    HIP_TRY(hipMemcpyAsync(stage.p, host, (size_t)n * rows * sizeof(Tp), hipMemcpyHostToDevice, c->stream));
+    const unsigned tb = 256, tg = (unsigned)((nP + tb - 1) / tb);
+    hipLaunchKernelGGL(tile_in_kernel<Tp>, dim3(tg), dim3(tb), 0, c->stream, (const Tp*)stage.p, dev, n, rows, nP);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -604,6 +618,22 @@ int mcmc_hip_set_chains(mcmc_hip_ctx* c, int64_t n_chains, const double* params,
     return 0;
 } MCMC_ABI_GUARD
 
+int mcmc_hip_set_state(mcmc_hip_ctx* c, const uint64_t* rng_state, const double* loglike, const double* mean,
+                       const int32_t* accept_counts) try {
+    if (int r = check_ctx(c)) return r;
+    if (!c->haveChains) return fail(MCMC_HIP_ESTATE, "set_state: call set_chains first");
+    HIP_TRY(hipSetDevice(c->device));
+    if (rng_state) {
+        for (long long i = 0; i < c->nChains; ++i)
+            if (!(rng_state[2 * i + 1] & 1u)) return fail(MCMC_HIP_EINVAL, "set_state: chain %lld: a pcg32 increment is odd by construction", i);
+        if (int r = upload_field<uint64_t>(c, rng_state, 2, c->S.rng)) return r;
+    }
+    if (loglike) { if (int r = upload_field<double>(c, loglike, 2, c->S.ll)) return r; }
+    if (mean) { if (int r = upload_field<double>(c, mean, c->dim, c->dMean.p)) return r; }
+    if (accept_counts) { if (int r = upload_field<int>(c, accept_counts, 1, c->S.nAccept)) return r; }
+    return 0;
+} MCMC_ABI_GUARD
+
 int mcmc_hip_step(mcmc_hip_ctx* c, int32_t n_steps, double beta, int32_t random_subspace) try {
     if (int r = check_ctx(c)) return r;
     if (!c->haveChains) return fail(MCMC_HIP_ESTATE, "step: call set_chains first");
@@ -755,7 +785,7 @@ int mcmc_hip_run(mcmc_hip_ctx* c, int32_t nSamples, int32_t nBurnin, int32_t nAd
     const int perLaunch = MCMC_STEPS_PER_LAUNCH;
     if (int r = run_schedule(c, betas, flags, 0, adjustEnd, perLaunch, &c->adjustS)) return r;
     if (int r = run_schedule(c, betas, flags, adjustEnd, betas.size(), perLaunch, &c->samplingS)) return r;
-    if (compute_mean && nAdjust + nSamples - nBurnin != 0) {           /* mcmc.h:1133-1134 */
+    if (compute_mean) {                                                /* mcmc.h:1133-1134 (1/0 = inf there too) */
         const long long count = (long long)c->dim * nP;
         const double f = 1.0 / (double)(nAdjust + nSamples - nBurnin);
         hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, c->dMean.p, count, f);
@@ -1027,7 +1057,7 @@ int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target
                      double target_slope, double target_Tinit, int64_t n, const uint64_t* chain_ids,
                      uint64_t first_chain_id, double* x, double* stepsizes, int32_t nSamples, int32_t nBurnin,
                      int32_t nAdjust, int32_t thinning, double* loglikes_out, double* samples_out,
-                     double* mean_out, int32_t* n_accept_out) try {
+                     double* mean_out, int32_t* n_accept_out, uint64_t* rng_state, int32_t mean_continue) try {
     const int dim = toy_dim(kind), nOut = toy_n_out(kind);
     if (dim < 0 || n < 1 || !x || !stepsizes) return fail(MCMC_HIP_EINVAL, "toy_run: bad arguments");
     if (nSamples < 0 || nBurnin < 0 || nAdjust < 0 || thinning < 1)
@@ -1048,8 +1078,15 @@ int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target
         for (int k = 0; k < dim; ++k) soa[(size_t)k * n + c] = x[c * dim + k];
     }
     DevBuf<double> dx, dss, dbeta, dll, dsamp, dmean;
-    DevBuf<uint64_t> dids;
+    DevBuf<uint64_t> dids, drng;
     DevBuf<int> dacc;
+    if (mean_continue && !mean_out) return fail(MCMC_HIP_EINVAL, "toy_run: mean_continue needs mean_out");
+    if (rng_state) {
+        for (int64_t c = 0; c < n; ++c)
+            if (!(rng_state[2 * c + 1] & 1u)) return fail(MCMC_HIP_EINVAL, "toy_run: chain %lld: a pcg32 increment is odd by construction", (long long)c);
+        if (int r = drng.alloc(2 * n)) return r;
+        HIP_TRY(hipMemcpy(drng.p, rng_state, 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
     if (int r = dx.alloc(soa.size())) return r;
     if (int r = dss.alloc(n)) return r;
     if (int r = dbeta.alloc(betas.size())) return r;
@@ -1057,7 +1094,15 @@ int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target
     if (int r = dacc.alloc(n)) return r;
     if (loglikes_out && nSaved > 0) { if (int r = dll.alloc((size_t)nSaved * n)) return r; }
     if (samples_out && nSaved > 0) { if (int r = dsamp.alloc((size_t)nSaved * nOut * n)) return r; }
-    if (mean_out) { if (int r = dmean.alloc((size_t)nOut * n)) return r; }
+    if (mean_out) {
+        if (int r = dmean.alloc((size_t)nOut * n)) return r;
+        if (mean_continue) {
+            std::vector<double> h((size_t)nOut * n);
+            for (int64_t c = 0; c < n; ++c)
+                for (int k = 0; k < nOut; ++k) h[(size_t)k * n + c] = mean_out[(size_t)c * nOut + k];
+            HIP_TRY(hipMemcpy(dmean.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
     HIP_TRY(hipMemcpy(dx.p, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dss.p, stepsizes, n * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dbeta.p, betas.data(), betas.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1065,10 +1110,10 @@ int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target
     const unsigned grid = (unsigned)((n + 255) / 256);
     if (kind == MCMC_TOY_MYLIKE1)
         hipLaunchKernelGGL(toy_run_kernel<TOY_MYLIKE1>, dim3(grid), dim3(256), 0, 0, dx.p, dss.p, (const uint64_t*)dids.p, (long long)n,
-                           difficulty, (const double*)dbeta.p, nSamples, nBurnin, nAdjust, thinning, dll.p, dsamp.p, dmean.p, dacc.p);
+                           difficulty, (const double*)dbeta.p, nSamples, nBurnin, nAdjust, thinning, dll.p, dsamp.p, dmean.p, dacc.p, drng.p, (int)mean_continue);
     else
         hipLaunchKernelGGL(toy_run_kernel<TOY_FOURGAUSS>, dim3(grid), dim3(256), 0, 0, dx.p, dss.p, (const uint64_t*)dids.p, (long long)n,
-                           difficulty, (const double*)dbeta.p, nSamples, nBurnin, nAdjust, thinning, dll.p, dsamp.p, dmean.p, dacc.p);
+                           difficulty, (const double*)dbeta.p, nSamples, nBurnin, nAdjust, thinning, dll.p, dsamp.p, dmean.p, dacc.p, drng.p, (int)mean_continue);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(soa.data(), dx.p, soa.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1076,6 +1121,7 @@ int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target
         for (int k = 0; k < dim; ++k) x[c * dim + k] = soa[(size_t)k * n + c];
     HIP_TRY(hipMemcpy(stepsizes, dss.p, n * sizeof(double), hipMemcpyDeviceToHost));
     if (n_accept_out) HIP_TRY(hipMemcpy(n_accept_out, dacc.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (rng_state) HIP_TRY(hipMemcpy(rng_state, drng.p, 2 * n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (dll.p) {
         std::vector<double> h((size_t)nSaved * n);
         HIP_TRY(hipMemcpy(h.data(), dll.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));

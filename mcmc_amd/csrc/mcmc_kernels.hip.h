@@ -1453,13 +1453,19 @@ __global__ __launch_bounds__(256) void toy_run_kernel(double* __restrict__ x, do
                                                       double difficulty, const double* __restrict__ betas,
                                                       int nSamples, int nBurnin, int nAdjust, int thinning,
                                                       double* __restrict__ recLL, double* __restrict__ recS,
-                                                      double* __restrict__ meanOut, int* __restrict__ nAcceptOut) {
+                                                      double* __restrict__ meanOut, int* __restrict__ nAcceptOut,
+                                                      uint64_t* __restrict__ rngIO, int meanContinue) {
     constexpr int DIM = KIND == TOY_MYLIKE1 ? 3 : 2;
     constexpr int NOUT = KIND == TOY_MYLIKE1 ? 4 : 2;                /* + the coordinate "max", test.h:37 */
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     Pcg32 rnd;
-    pcg32_seed(rnd.state, rnd.inc, 0, ids[c]);                       /* rnd(0, chainid), mcmc.h:999 */
+    if (rngIO) {                                                     /* a chain's rnd lives across run() calls, mcmc.h:994 */
+        rnd.state = rngIO[2 * c];
+        rnd.inc = rngIO[2 * c + 1];
+    } else {
+        pcg32_seed(rnd.state, rnd.inc, 0, ids[c]);                   /* rnd(0, chainid), mcmc.h:999 */
+    }
     double cur[3] = {0, 0, 0}, prop[3] = {0, 0, 0};
 #pragma unroll
     for (int k = 0; k < DIM; ++k) cur[k] = x[(long long)k * n + c];
@@ -1468,6 +1474,10 @@ __global__ __launch_bounds__(256) void toy_run_kernel(double* __restrict__ x, do
     int nAccept = 0, slot = 0;
     /* mean = deep copy of the evaluated initial state (mcmc.h:1002) */
     double mean[4] = {cur[0], cur[1], cur[2], fmax(fmax(cur[0], cur[1]), cur[2])};
+    if (meanOut && meanContinue) {                                   /* a later run() adds to the mean it has */
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) mean[k == DIM && NOUT > DIM ? 3 : k] = meanOut[(long long)k * n + c];
+    }
     for (int i = 0; i < nSamples + nAdjust; ++i) {                   /* mcmc.h:1023 */
         const double beta = betas[i];
         if (i == nAdjust) nAccept = 0;                               /* mcmc.h:1032 */
@@ -1519,9 +1529,9 @@ __global__ __launch_bounds__(256) void toy_run_kernel(double* __restrict__ x, do
     for (int k = 0; k < DIM; ++k) x[(long long)k * n + c] = cur[k];
     stepsizes[c] = sf;
     nAcceptOut[c] = nAccept;
+    if (rngIO) rngIO[2 * c] = rnd.state;
     if (meanOut) {                                                   /* mcmc.h:1133-1134 */
-        const int cnt = nAdjust + nSamples - nBurnin;
-        const double f = cnt != 0 ? 1.0 / (double)cnt : 1.0;
+        const double f = 1.0 / (double)(nAdjust + nSamples - nBurnin);   /* 1/0 = inf there too */
 #pragma unroll
         for (int k = 0; k < DIM; ++k) meanOut[(long long)k * n + c] = mean[k] * f;
         if constexpr (NOUT > DIM) meanOut[(long long)DIM * n + c] = mean[3] * f;

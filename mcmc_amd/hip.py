@@ -23,6 +23,7 @@ SYMBOLS = [
     "mcmc_hip_last_error", "mcmc_hip_device_count", "mcmc_host_make_response_tables",
     "mcmc_host_default_disease_params", "mcmc_host_perturb_ics", "mcmc_hip_create",
     "mcmc_hip_destroy", "mcmc_hip_set_tables", "mcmc_hip_set_data", "mcmc_hip_set_precision", "mcmc_hip_set_chains",
+    "mcmc_hip_set_state",
     "mcmc_hip_run", "mcmc_hip_step", "mcmc_hip_n_saved", "mcmc_hip_dim", "mcmc_hip_size",
     "mcmc_hip_n_chains", "mcmc_hip_get_params", "mcmc_hip_get_loglike", "mcmc_hip_get_stepsizes",
     "mcmc_hip_get_accept_counts", "mcmc_hip_get_rng_state", "mcmc_hip_get_loglikes",
@@ -81,6 +82,7 @@ def lib():
     L.mcmc_hip_set_data.argtypes = [vp, dp, dp]
     L.mcmc_hip_set_precision.argtypes = [vp, C.c_int32]
     L.mcmc_hip_set_chains.argtypes = [vp, C.c_int64, dp, dp, C.POINTER(C.c_uint64), C.c_uint64]
+    L.mcmc_hip_set_state.argtypes = [vp, C.POINTER(C.c_uint64), dp, dp, C.POINTER(C.c_int32)]
     L.mcmc_hip_run.argtypes = [vp] + [C.c_int32] * 6
     L.mcmc_hip_step.argtypes = [vp, C.c_int32, C.c_double, C.c_int32]
     L.mcmc_hip_n_saved.argtypes = [C.c_int32] * 4
@@ -111,7 +113,7 @@ def lib():
     L.mcmc_hip_toy_eval.argtypes = [C.c_int, C.c_int32, C.c_double, C.c_int64, dp, dp]
     L.mcmc_hip_toy_run.argtypes = [C.c_int, C.c_int32, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_double,
                                    C.c_int64, C.POINTER(C.c_uint64), C.c_uint64, dp, dp, C.c_int32, C.c_int32,
-                                   C.c_int32, C.c_int32, dp, dp, dp, C.POINTER(C.c_int32)]
+                                   C.c_int32, C.c_int32, dp, dp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.c_int32]
     _lib = L
     return L
 
@@ -156,7 +158,7 @@ def toy_eval(kind, x, difficulty=1.0, device=0):
 
 
 def toy_run(kind, x0, n_samples, n_burnin, n_adjust, thinning, difficulty=1.0, target="plain", T=1.0, slope=0.0,
-            Tinit=1.0, stepsizes=1.0, chain_ids=None, first_chain_id=0, device=0):
+            Tinit=1.0, stepsizes=1.0, chain_ids=None, first_chain_id=0, device=0, rng_state=None, mean_in=None):
     """MetropolisChain::run for n toy chains on the GPU (test.cpp:27-40 is kind='mylike1',
     one chain, id 0, x0 = (1,1,1), run(100000, 10, 500, 5)).  Returns a dict; `samples` and
     `mean` have n_out columns (MyLike1: position + its coordinate "max")."""
@@ -169,14 +171,17 @@ def toy_run(kind, x0, n_samples, n_burnin, n_adjust, thinning, difficulty=1.0, t
     ll = np.zeros((n, ns))
     n_out = L.mcmc_hip_toy_n_out(TOY[kind])
     samples = np.zeros((n, ns, n_out))
-    mean = np.zeros((n, n_out))
+    mean = np.zeros((n, n_out)) if mean_in is None else np.array(mean_in, dtype=np.float64, order="C").reshape(n, n_out)
+    rng = None if rng_state is None else np.array(rng_state, dtype=np.uint64, order="C").reshape(n, 2)
     acc = np.zeros(n, dtype=np.int32)
     ids = None if chain_ids is None else np.ascontiguousarray(chain_ids, dtype=np.uint64)
     _check(L.mcmc_hip_toy_run(device, TOY[kind], difficulty, _KIND[target], T, slope, Tinit, n,
                               ids.ctypes.data_as(C.POINTER(C.c_uint64)) if ids is not None else None,
                               first_chain_id, _dp(x), _dp(ss), n_samples, n_burnin, n_adjust, thinning,
-                              _dp(ll), _dp(samples), _dp(mean), acc.ctypes.data_as(C.POINTER(C.c_int32))))
-    return dict(x=x, stepsizes=ss, loglikes=ll, samples=samples, mean=mean, n_accept=acc)
+                              _dp(ll), _dp(samples), _dp(mean), acc.ctypes.data_as(C.POINTER(C.c_int32)),
+                              rng.ctypes.data_as(C.POINTER(C.c_uint64)) if rng is not None else None,
+                              0 if mean_in is None else 1))
+    return dict(x=x, stepsizes=ss, loglikes=ll, samples=samples, mean=mean, n_accept=acc, rng_state=rng)
 
 
 class CovidSampler:
@@ -245,6 +250,16 @@ class CovidSampler:
             self._h, n, _dp(params), _dp(ss),
             ids.ctypes.data_as(C.POINTER(C.c_uint64)) if ids is not None else None, first_chain_id))
         self.n_chains = n
+
+    def set_state(self, rng_state=None, loglike=None, mean=None, accept_counts=None):
+        """mcmc_hip_set_state: continue chains that another context / process advanced."""
+        r = None if rng_state is None else np.ascontiguousarray(rng_state, dtype=np.uint64)
+        l = None if loglike is None else np.ascontiguousarray(loglike, dtype=np.float64)
+        m = None if mean is None else np.ascontiguousarray(mean, dtype=np.float64)
+        a = None if accept_counts is None else np.ascontiguousarray(accept_counts, dtype=np.int32)
+        _check(lib().mcmc_hip_set_state(
+            self._h, r.ctypes.data_as(C.POINTER(C.c_uint64)) if r is not None else None, _dp(l), _dp(m),
+            a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None))
 
     def run(self, n_samples, n_burnin, n_adjust, thinning, record_samples=False, compute_mean=False):
         _check(lib().mcmc_hip_run(self._h, n_samples, n_burnin, n_adjust, thinning,

@@ -23,6 +23,7 @@
 #pragma once
 
 #include <algorithm>
+#include <numeric>
 #include <cmath>
 #include <cstdint>
 #include <fstream>
@@ -34,6 +35,8 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <unordered_set>
 #include <vector>
 
 #include "mcmc_hip.h"
@@ -62,6 +65,11 @@ struct pcg32 {
         uint32_t x = (uint32_t)(((old >> 18u) ^ old) >> 27u), r = (uint32_t)(old >> 59u);
         return (x >> r) | (x << ((~r + 1u) & 31));
     }
+    float nextFloat() {
+        union { uint32_t u; float f; } x;
+        x.u = (nextUInt() >> 9) | 0x3f800000u;
+        return x.f - 1.0f;
+    }
     double nextDouble() {
         union { uint64_t u; double d; } x;
         x.u = ((uint64_t)nextUInt() << 20) | 0x3ff0000000000000ULL;
@@ -77,11 +85,29 @@ inline void hip_check(int rc, const char* where) {
     if (rc != 0) throw HipError(rc, std::string(where) + ": " + mcmc_hip_last_error());
 }
 
+/* mcmc.h:55-58 */
+#define HAS_STEP std::shared_ptr<SubspaceState> copy() const override {\
+    return std::make_shared<std::remove_const_t<std::remove_reference_t<decltype(*this)>>>(*this);}
+using SharedParams = std::map<std::string, std::vector<Float>>;
+
 /* ------------------------------------------------------------------ SubspaceState ---- */
-/* mcmc.h:62-183: named ragged coords, loglike, stepsizeCorrectionFac, fixed set.  The
- * virtuals that evaluate or step a likelihood on the CPU are not part of this mirror. */
+/* mcmc.h:62-183: the plugin interface -- named ragged coords, loglike, stepsizeCorrectionFac,
+ * fixed set, and the virtuals a model overrides (eval, step, the initial-condition trio,
+ * compute_derived_late, force_bounds), with the reference's signatures and default bodies, so
+ * that a likelihood written against the reference compiles against this header.  The device path
+ * never calls a user's eval/step: it runs the compositions State::supported() lists, and any
+ * other composition is refused there, loudly, instead of being stepped on the CPU. */
 class SubspaceState {
 public:
+    using Proposal = std::pair<std::shared_ptr<SubspaceState>, Float>;         /* mcmc.h:92 */
+    virtual void eval(const SharedParams&) { loglike = 0; }                    /* mcmc.h:96-98 */
+    virtual void compute_derived_late(const SharedParams&) {}                  /* mcmc.h:103-104 */
+    virtual Proposal step(pcg32&, const SharedParams&) const { return Proposal{copy(), 1}; } /* mcmc.h:107-110 */
+    virtual std::vector<Float> sampleInitialConditions(pcg32&) { return {}; }  /* mcmc.h:112-114 */
+    virtual std::vector<Float> getInitialConditions() { return {}; }           /* mcmc.h:116-118 */
+    virtual void setInitialConditions(const std::vector<Float>&) {}            /* mcmc.h:120-121 */
+    bool isFixed(std::pair<size_t, size_t> index) const { return fixed.find(index) != fixed.end(); } /* mcmc.h:158-160 */
+
     Float loglike = 0;
     Float stepsizeCorrectionFac = 1;
     bool derivedOnShared = false;
@@ -125,6 +151,8 @@ public:
 protected:
     std::vector<std::vector<Float>> coords = {};
     std::map<std::string, size_t> names = {};
+    std::vector<std::string> requestedSharedNames;                /* mcmc.h:175 */
+    std::unordered_set<std::string> offeredSharedNames;           /* mcmc.h:178 */
     size_t nDerived = 0;
 };
 
@@ -132,7 +160,9 @@ protected:
 class SmoothnessPrior : public SubspaceState {
 public:
     SmoothnessPrior(const std::string& functionName, Float smoothnessScale, Float scale)
-        : SubspaceState({}), L(scale), Lsmooth(smoothnessScale), functionName(functionName) {}
+        : SubspaceState({}), L(scale), Lsmooth(smoothnessScale), functionName(functionName) {
+        requestedSharedNames.push_back(functionName);                 /* mcmc.h:190 */
+    }
     Float L, Lsmooth;
     std::string functionName;
     std::shared_ptr<SubspaceState> copy() const override { return std::make_shared<SmoothnessPrior>(*this); }
@@ -282,7 +312,6 @@ public:
     /* coords that eval() sets besides loglike */
     virtual void refresh_derived() {}
     void unpack(const Float* x) { for (auto& v : coords[0]) v = *x++; refresh_derived(); }
-    virtual std::vector<Float> sampleInitialConditions(pcg32&) { return {}; }   /* mcmc.h:112-114 */
 };
 class MyLike1 : public ToyLikelihood {
 public:
@@ -299,6 +328,8 @@ public:
         unpack(ret.data());
         return ret;
     }
+    std::vector<Float> getInitialConditions() override { return coords[0]; }                  /* test.h:124-126 */
+    void setInitialConditions(const std::vector<Float>& ics) override { if (ics.size() >= 2) unpack(ics.data()); } /* test.h:127-130 */
     std::shared_ptr<SubspaceState> copy() const override { return std::make_shared<FourGaussians>(*this); }
 };
 
@@ -362,10 +393,23 @@ public:
 struct BatchResults {
     size_t n = 0, dim = 0, nOut = 0;
     int nSaved = 0;
-    std::vector<Float> lls, params, mean, fll, fss;      /* [n][nSaved] [n][dim] [n][nOut] [n][2] [n] */
+    bool recorded = false;                               /* the saved points stayed on the device / in the backend */
+    std::vector<Float> lls, params, mean, fll, fss;      /* [n][nSaved] [n][dim] [n][nOut] (empty: no mean) [n][2] [n] */
     std::vector<int32_t> acc;
-    std::vector<std::vector<Float>> saved;               /* [nSaved] of [n][nOut] */
+    std::vector<uint64_t> rng;                           /* [n][2] pcg32 (state, inc) at the end of the run */
     std::vector<Float> diagnostics;                      /* mcmc_hip_diagnostics (covid) */
+};
+
+/* What a run records and where it starts from.  recordSamples: keep the saved points (the
+ * reference's `ics`, mcmc.h:1043, + `samples`, mcmc.h:1060-1061); computeMean: mcmc.h:1064-1065;
+ * rng [n][2] / meanIn [n][nOut]: continue these generator streams / running means instead of
+ * seeding pcg32(0, id) and starting the mean at the current point -- a MetropolisChain keeps both
+ * across run() calls (mcmc.h:994-1003). */
+struct RunOptions {
+    bool recordSamples = true;
+    bool computeMean = false;
+    const uint64_t* rng = nullptr;
+    const Float* meanIn = nullptr;
 };
 
 /* The device work behind one supported State composition. */
@@ -381,7 +425,11 @@ public:
     virtual void derive(size_t, const Float*, Float*) { throw std::logic_error("derive: not a covid state"); }
     /* MetropolisChain::run for n chains with ids firstId.. */
     virtual void run(BatchResults& R, size_t n, const Float* x, const Float* ss, uint64_t firstId, int nSamples,
-                     int nBurnin, int nAdjust, int thinning) = 0;
+                     int nBurnin, int nAdjust, int thinning, const RunOptions& opt) = 0;
+    /* the saved points of the last run (recordSamples): chain i as [nSaved][nOut], saved point s of
+     * every chain as [n][nOut] -- fetched on request, not with every run */
+    virtual std::vector<Float> chain_samples(size_t i) = 0;
+    virtual std::vector<Float> sample_all(int s) = 0;
     /* Tempering ladders (extension, no counterpart in the reference): chains [L*K, (L+1)*K) form ladder L on the
      * temperatures `temps`; nRounds x (stepsPerRound MH steps, one exchange round).  rungs[i] = the rung chain i
      * ends on; swapAcc/swapProp [K-1] per neighbouring pair. */
@@ -404,27 +452,42 @@ public:
         hip_check(mcmc_hip_derive(eng.ctx, (int64_t)n, x, curves), "mcmc_hip_derive");
     }
     void run(BatchResults& R, size_t n, const Float* x, const Float* ss, uint64_t firstId, int nSamples, int nBurnin,
-             int nAdjust, int thinning) override {
+             int nAdjust, int thinning, const RunOptions& opt) override {
         const size_t d = dim();
         hip_check(mcmc_hip_set_chains(eng.ctx, (int64_t)n, x, ss, nullptr, firstId), "mcmc_hip_set_chains");
-        /* the parameter samples are what the reference keeps as `ics` of every saved point
-         * (mcmc.h:1042-1045), whatever recordSamples says */
-        hip_check(mcmc_hip_run(eng.ctx, nSamples, nBurnin, nAdjust, thinning, 1, 1), "mcmc_hip_run");
+        if (opt.rng || opt.meanIn)
+            hip_check(mcmc_hip_set_state(eng.ctx, opt.rng, nullptr, opt.meanIn, nullptr), "mcmc_hip_set_state");
+        hip_check(mcmc_hip_run(eng.ctx, nSamples, nBurnin, nAdjust, thinning, opt.recordSamples ? 1 : 0,
+                               opt.computeMean ? 1 : 0), "mcmc_hip_run");
         const int nSaved = mcmc_hip_n_saved(nSamples, nBurnin, nAdjust, thinning);
         R = BatchResults{};
-        R.lls.assign(n * (size_t)std::max(nSaved, 1), 0); R.params.assign(n * d, 0); R.mean.assign(n * d, 0);
-        R.fll.assign(n * 2, 0); R.fss.assign(n, 0); R.acc.assign(n, 0);
+        R.lls.assign(n * (size_t)std::max(nSaved, 1), 0); R.params.assign(n * d, 0);
+        R.fll.assign(n * 2, 0); R.fss.assign(n, 0); R.acc.assign(n, 0); R.rng.assign(n * 2, 0);
         if (nSaved > 0) hip_check(mcmc_hip_get_loglikes(eng.ctx, R.lls.data()), "mcmc_hip_get_loglikes");
         hip_check(mcmc_hip_get_params(eng.ctx, R.params.data()), "mcmc_hip_get_params");
-        hip_check(mcmc_hip_get_mean(eng.ctx, R.mean.data()), "mcmc_hip_get_mean");
+        if (opt.computeMean) {
+            R.mean.assign(n * d, 0);
+            hip_check(mcmc_hip_get_mean(eng.ctx, R.mean.data()), "mcmc_hip_get_mean");
+        }
         hip_check(mcmc_hip_get_loglike(eng.ctx, R.fll.data()), "mcmc_hip_get_loglike");
         hip_check(mcmc_hip_get_stepsizes(eng.ctx, R.fss.data()), "mcmc_hip_get_stepsizes");
         hip_check(mcmc_hip_get_accept_counts(eng.ctx, R.acc.data()), "mcmc_hip_get_accept_counts");
-        R.saved.assign(nSaved, std::vector<Float>(n * d));
-        for (int s = 0; s < nSaved; ++s) hip_check(mcmc_hip_get_sample_all(eng.ctx, s, R.saved[s].data()), "mcmc_hip_get_sample_all");
+        hip_check(mcmc_hip_get_rng_state(eng.ctx, R.rng.data()), "mcmc_hip_get_rng_state");
         R.diagnostics.assign(4 + 2 * d, 0);
         hip_check(mcmc_hip_diagnostics(eng.ctx, R.diagnostics.data()), "mcmc_hip_diagnostics");
-        R.n = n; R.dim = d; R.nOut = d; R.nSaved = nSaved;
+        R.n = n; R.dim = d; R.nOut = d; R.nSaved = nSaved; R.recorded = opt.recordSamples && nSaved > 0;
+        lastSaved = R.recorded ? nSaved : 0; lastN = n;
+    }
+    std::vector<Float> chain_samples(size_t i) override {
+        std::vector<Float> out((size_t)lastSaved * dim());
+        if (lastSaved > 0) hip_check(mcmc_hip_get_samples(eng.ctx, (int64_t)i, 0, (int32_t)dim(), out.data()), "mcmc_hip_get_samples");
+        return out;
+    }
+    std::vector<Float> sample_all(int s) override {
+        if (s < 0 || s >= lastSaved) throw std::out_of_range("sample_all: no such saved point");
+        std::vector<Float> out(lastN * dim());
+        hip_check(mcmc_hip_get_sample_all(eng.ctx, s, out.data()), "mcmc_hip_get_sample_all");
+        return out;
     }
     void run_tempered(BatchResults& R, size_t n, const Float* x, const Float* ss, uint64_t firstId,
                       const std::vector<Float>& temps, uint64_t swapSeed, int nRounds, int stepsPerRound,
@@ -446,8 +509,12 @@ public:
         R.diagnostics.assign(4 + 2 * d, 0);
         hip_check(mcmc_hip_diagnostics(eng.ctx, R.diagnostics.data()), "mcmc_hip_diagnostics");
         R.n = n; R.dim = d; R.nOut = d; R.nSaved = 0;
+        lastSaved = 0; lastN = n;
     }
     Engine eng;
+private:
+    int lastSaved = 0;
+    size_t lastN = 0;
 };
 
 class ToyBackend : public Backend {
@@ -465,27 +532,47 @@ public:
         for (size_t i = 0; i < n; ++i) { ll[2 * i] = l[i]; ll[2 * i + 1] = 0; }
     }
     void run(BatchResults& R, size_t n, const Float* x, const Float* ss, uint64_t firstId, int nSamples, int nBurnin,
-             int nAdjust, int thinning) override {
+             int nAdjust, int thinning, const RunOptions& opt) override {
         const int nSaved = mcmc_hip_n_saved(nSamples, nBurnin, nAdjust, thinning);
         R = BatchResults{};
         R.params.assign(x, x + n * d);
         R.fss.assign(ss, ss + n);
-        R.lls.assign(n * (size_t)std::max(nSaved, 1), 0); R.mean.assign(n * no, 0); R.acc.assign(n, 0);
-        std::vector<Float> samples(n * (size_t)std::max(nSaved, 1) * no);
+        R.lls.assign(n * (size_t)std::max(nSaved, 1), 0); R.acc.assign(n, 0);
+        R.rng.assign(n * 2, 0);
+        for (size_t c = 0; c < n; ++c) {                 /* continue the given streams, else rnd(0, id), mcmc.h:999 */
+            if (opt.rng) { R.rng[2 * c] = opt.rng[2 * c]; R.rng[2 * c + 1] = opt.rng[2 * c + 1]; }
+            else { pcg32 r(0, firstId + c); R.rng[2 * c] = r.state; R.rng[2 * c + 1] = r.inc; }
+        }
+        if (opt.computeMean) {
+            R.mean.assign(n * no, 0);
+            if (opt.meanIn) R.mean.assign(opt.meanIn, opt.meanIn + n * no);
+        }
+        samples.assign(opt.recordSamples ? n * (size_t)std::max(nSaved, 1) * no : 0, 0);
         hip_check(mcmc_hip_toy_run(device, kind, difficulty, (int32_t)spec.kind, spec.T, spec.slope, spec.Tinit, (int64_t)n,
                                    nullptr, firstId, R.params.data(), R.fss.data(), nSamples, nBurnin, nAdjust, thinning,
-                                   R.lls.data(), samples.data(), R.mean.data(), R.acc.data()), "mcmc_hip_toy_run");
-        R.saved.assign(nSaved, std::vector<Float>(n * no));
-        for (int s = 0; s < nSaved; ++s)
-            for (size_t c = 0; c < n; ++c)
-                std::copy(samples.begin() + (c * nSaved + s) * no, samples.begin() + (c * nSaved + s + 1) * no,
-                          R.saved[s].begin() + c * no);
+                                   R.lls.data(), opt.recordSamples ? samples.data() : nullptr,
+                                   opt.computeMean ? R.mean.data() : nullptr, R.acc.data(), R.rng.data(),
+                                   (opt.computeMean && opt.meanIn) ? 1 : 0), "mcmc_hip_toy_run");
         R.fll.assign(n * 2, 0);
         eval(n, R.params.data(), R.fll.data());
-        R.n = n; R.dim = d; R.nOut = no; R.nSaved = nSaved;
+        R.n = n; R.dim = d; R.nOut = no; R.nSaved = nSaved; R.recorded = opt.recordSamples && nSaved > 0;
+        lastSaved = R.recorded ? nSaved : 0; lastN = n;
+    }
+    std::vector<Float> chain_samples(size_t i) override {
+        return std::vector<Float>(samples.begin() + i * lastSaved * no, samples.begin() + (i + 1) * lastSaved * no);
+    }
+    std::vector<Float> sample_all(int s) override {
+        if (s < 0 || s >= lastSaved) throw std::out_of_range("sample_all: no such saved point");
+        std::vector<Float> out(lastN * no);
+        for (size_t c = 0; c < lastN; ++c)
+            std::copy(samples.begin() + (c * lastSaved + s) * no, samples.begin() + (c * lastSaved + s + 1) * no, out.begin() + c * no);
+        return out;
     }
 private:
     int kind; Float difficulty; TargetSpec spec; int device; int d = 0, no = 0;
+    std::vector<Float> samples;                          /* [n][nSaved][nOut] of the last recorded run */
+    int lastSaved = 0;
+    size_t lastN = 0;
 };
 
 /* ------------------------------------------------------------------------- State ---- */
@@ -701,13 +788,16 @@ struct ChainRecord {
     Float stepsize = 1;
     int nAccept = 0;
 
-    /* chain `i` of a batched run */
-    void take(const BatchResults& R, size_t i) {
+    /* chain `i` of a batched run: its loglikes and saved points are APPENDED, as run() push_backs
+     * them (mcmc.h:1039-1043); the mean and the end state replace what was there */
+    void take(const BatchResults& R, size_t i, Backend& be) {
         const size_t ns = (size_t)R.nSaved;
-        loglikes.assign(R.lls.begin() + i * ns, R.lls.begin() + (i + 1) * ns);
-        ics.clear();
-        for (size_t s = 0; s < ns; ++s) ics.emplace_back(R.saved[s].begin() + i * R.nOut, R.saved[s].begin() + (i + 1) * R.nOut);
-        mean.assign(R.mean.begin() + i * R.nOut, R.mean.begin() + (i + 1) * R.nOut);
+        loglikes.insert(loglikes.end(), R.lls.begin() + i * ns, R.lls.begin() + (i + 1) * ns);
+        if (R.recorded) {
+            const std::vector<Float> pts = be.chain_samples(i);
+            for (size_t s = 0; s < ns; ++s) ics.emplace_back(pts.begin() + s * R.nOut, pts.begin() + (s + 1) * R.nOut);
+        }
+        if (!R.mean.empty()) mean.assign(R.mean.begin() + i * R.nOut, R.mean.begin() + (i + 1) * R.nOut);
         finalParams.assign(R.params.begin() + i * R.dim, R.params.begin() + (i + 1) * R.dim);
         finalLL[0] = R.fll[2 * i]; finalLL[1] = R.fll[2 * i + 1];
         stepsize = R.fss[i];
@@ -726,12 +816,14 @@ struct ChainRecord {
  * ChainManager::get_chain carries what the manager's batched run recorded for it. */
 class MetropolisChain {
 public:
-    MetropolisChain(std::shared_ptr<Target> target, int chainid) : target(target), id(chainid) {}
+    MetropolisChain(std::shared_ptr<Target> target, int chainid) : rnd(0, (uint64_t)chainid), target(target), id(chainid) {}
 
     Float weight = 1;
-    bool computeMean = true;
+    bool computeMean = false;                           /* mcmc.h:990 */
     bool recordSamples = true;
     bool writeSamplesToDisk = false;
+    pcg32 rnd;                                          /* seeded ONCE, rnd(0, chainid) (mcmc.h:994,999): a later
+                                                           run() goes on drawing where the last one stopped */
     std::shared_ptr<Target> target;
     int id = 0;
     ChainRecord rec;
@@ -748,9 +840,18 @@ public:
         const Float ss = st.state[0]->stepsizeCorrectionFac;
         std::cout << "Starting to adjust and sample.\n";
         BatchResults R;
-        be->run(R, 1, x.data(), &ss, (uint64_t)id, nSamples, nBurnin, nAdjust, thinning);
-        rec.take(R, 0);
-        if (!computeMean) rec.mean.clear();
+        /* the saved points are the chain's `ics`, which the reference keeps whatever recordSamples says
+         * (mcmc.h:1043); the generator stream and, with computeMean, the running mean carry over from
+         * the previous run() of this chain */
+        RunOptions opt;
+        opt.recordSamples = true;
+        opt.computeMean = computeMean;
+        const uint64_t stream[2] = {rnd.state, rnd.inc};
+        opt.rng = stream;
+        if (computeMean && rec.mean.size() == be->n_out()) opt.meanIn = rec.mean.data();
+        be->run(R, 1, x.data(), &ss, (uint64_t)id, nSamples, nBurnin, nAdjust, thinning, opt);
+        rec.take(R, 0, *be);
+        rnd.state = R.rng[0]; rnd.inc = R.rng[1];
         haveSamples = recordSamples || writeSamplesToDisk;
         rec.apply_to(st);
         if (st.disease()) {
@@ -974,6 +1075,7 @@ public:
     void run_tempered(const std::vector<Float>& temps, size_t nRounds, size_t stepsPerRound, uint64_t swapSeed) {
         chains.clear();
         nRun = 0;
+        lastBackend.reset();
         std::string why;
         if (!target->state || !target->state->supported(&why)) { std::cout << "ChainManager: " << why << ".\n"; return; }
         const size_t n = chainICs.size(), K = temps.size();
@@ -993,6 +1095,7 @@ public:
         be->run_tempered(R, n, flat.data(), ss.data(), 1, temps, swapSeed, (int)nRounds, (int)stepsPerRound, rungs,
                          swapAccepted, swapProposed);
         last_diagnostics = R.diagnostics;
+        lastBackend = std::move(be);
         nRun = n;
         std::cout << "Tempered chain runs completed." << std::endl << std::endl;
     }
@@ -1024,10 +1127,19 @@ public:
         std::cout << "Reevaluation completed." << std::endl << std::endl;
     }
     size_t n_chains() const { return chainICs.size(); }
+    /* Every chain keeps the points it saves (its `ics`, mcmc.h:1043) on the device, and they are only
+     * copied to the host for a chain that is asked for (get_chain, reevaluate_all, saved_sample).
+     * false: record the log-likelihood trace only -- for very large ensembles whose points nobody reads
+     * (no reevaluate_all afterwards). */
+    bool recordInitialConditions = true;
     /* bulk views of the last run, chain-major: loglikes [n][nSaved], saved sample s [n][nOut] */
     const std::vector<Float>& all_loglikes() const { return R.lls; }
     const std::vector<Float>& all_final_params() const { return R.params; }
-    const std::vector<Float>& saved_sample(int s) const { return R.saved.at(s); }
+    /* saved point s of every chain, fetched from the device on request */
+    std::vector<Float> saved_sample(int s) const {
+        if (!lastBackend || !R.recorded) throw std::out_of_range("ChainManager::saved_sample: the last run recorded no points");
+        return lastBackend->sample_all(s);
+    }
     int n_saved() const { return R.nSaved; }
     int n_dim() const { return (int)R.nOut; }
     int chain_weight(size_t i) const { return chainICs.at(i).second; }
@@ -1081,37 +1193,42 @@ protected:
         if (t) st.setInitialConditions(out.back().first);
     }
 
-    /* mcmc.h:1599-1650: draw nChain distinct candidates from the discrete distribution of
-     * their probabilities; a candidate drawn again raises its chain's weight instead */
-    void bootstrap(pcg32& rnd, std::vector<std::pair<ICs, Float>>& trialChainICs) {
-        std::vector<double> discreteCDF;
-        double total = 0.0;
-        double maxsofar = -1e20;
-        for (auto& t : trialChainICs) if (t.second > maxsofar) maxsofar = t.second;
+    /* mcmc.h:1599-1650: importance resampling of the candidates.  Candidate k carries the log weight
+     * lp_k (log target density minus the density it was drawn from); nChain DISTINCT candidates are
+     * drawn with probability proportional to w_k = exp(lp_k - max lp) -- the best one at w = 1, so that
+     * log weights of order -1e7 do not all underflow -- and a candidate drawn again raises the integer
+     * weight of the chain it already seeds.  Draw order, arithmetic and messages follow the reference:
+     * one nextDouble() per draw, scaled by the running total, located in the running sums by
+     * upper_bound, the last sum lifted to 1.000001 x total against rounding. */
+    void bootstrap(pcg32& rnd, std::vector<std::pair<ICs, Float>>& cand) {
+        const size_t m = cand.size();
+        Float top = -1e20;                                   /* the reference's floor for the maximum */
+        for (const auto& c : cand) top = std::max(top, c.second);
         std::cout << "Selecting " << nChain << " chains according to the target density." << std::endl;
-        std::cout << "Highest log probability in set: " << maxsofar << "\n";
-        for (auto& t : trialChainICs) { t.second = std::exp(t.second - maxsofar); total += t.second; }
-        discreteCDF.push_back(trialChainICs[0].second);
-        for (size_t i = 1; i < trialChainICs.size(); ++i) discreteCDF.push_back(discreteCDF[i - 1] + trialChainICs[i].second);
-        discreteCDF.back() = 1.000001 * total;
-        std::map<size_t, size_t> old2new;
-        /* the reference loops until nChain DISTINCT candidates are found, which never ends
-         * when fewer exist; stop after a bounded number of draws instead */
+        std::cout << "Highest log probability in set: " << top << "\n";
+        std::vector<double> w(m), upTo(m);
+        for (size_t k = 0; k < m; ++k) w[k] = std::exp(cand[k].second - top);
+        const double total = std::accumulate(w.begin(), w.end(), 0.0);          /* left to right, like the reference */
+        std::partial_sum(w.begin(), w.end(), upTo.begin());
+        upTo.back() = 1.000001 * total;
+        std::vector<long> seeds(m, -1);                      /* candidate -> the chain it seeds, -1: none yet */
+        /* the reference draws until nChain distinct candidates are found, which never ends when fewer
+         * exist: stop after a bounded number of draws instead */
         const size_t maxDraws = 1000 * std::max<size_t>(nChain, 1) + 1000;
-        size_t draws = 0;
-        for (size_t i = 0; i < nChain && draws < maxDraws; ++i, ++draws) {
-            double x = rnd.nextDouble() * total;
-            auto iter = std::upper_bound(discreteCDF.begin(), discreteCDF.end(), x);
-            size_t idx = iter - discreteCDF.begin();
-            std::cout << "Relative loglikelihood of chain drawn is " << std::log(trialChainICs[idx].second) << "\n";
-            if (old2new.find(idx) == old2new.end()) {
-                chainICs.push_back(std::make_pair(trialChainICs[idx].first, 1));
-                old2new[idx] = chainICs.size() - 1;
+        size_t found = 0;
+        for (size_t draws = 0; found < nChain && draws < maxDraws; ++draws) {
+            const double x = rnd.nextDouble() * total;
+            const size_t k = std::min<size_t>(std::upper_bound(upTo.begin(), upTo.end(), x) - upTo.begin(), m - 1);
+            std::cout << "Relative loglikelihood of chain drawn is " << std::log(w[k]) << "\n";
+            if (seeds[k] < 0) {
+                seeds[k] = (long)chainICs.size();
+                chainICs.emplace_back(cand[k].first, 1);
+                ++found;
             } else {
-                std::cout << "Note: same chain " << old2new[idx] << " that has been picked " << chainICs[old2new[idx]].second
-                          << " times was picked again. New chain weight: " << chainICs[old2new[idx]].second + 1 << std::endl;
-                chainICs[old2new[idx]].second += 1;
-                --i;
+                auto& chain = chainICs[(size_t)seeds[k]];
+                std::cout << "Note: same chain " << seeds[k] << " that has been picked " << chain.second
+                          << " times was picked again. New chain weight: " << chain.second + 1 << std::endl;
+                ++chain.second;
             }
         }
         std::cout << "Selection completed." << std::endl << std::endl;
@@ -1120,6 +1237,7 @@ protected:
     /* what the last batched run recorded, for all chains; a MetropolisChain object (with its
      * own deep-copied Target, mcmc.h:1479,1520) is only built when somebody asks for it */
     BatchResults R;
+    std::unique_ptr<Backend> lastBackend;                /* holds the saved points of the last run */
     size_t nRun = 0;
     std::map<size_t, MetropolisChain> chains;
     std::vector<int32_t> rungs;
@@ -1132,7 +1250,8 @@ protected:
         MetropolisChain c(tar, (int)i + 1);
         c.recordSamples = false;
         c.weight = chainICs[i].second;
-        c.rec.take(R, i);
+        c.rec.take(R, i, *lastBackend);
+        c.rnd.state = R.rng[2 * i]; c.rnd.inc = R.rng[2 * i + 1];
         c.rec.apply_to(*tar->state);
         return chains.emplace(i, std::move(c)).first->second;
     }
@@ -1140,6 +1259,7 @@ protected:
     void run_impl(int nSteps, int nAdjust, int thinning, bool useStepsizes) {
         chains.clear();
         nRun = 0;
+        lastBackend.reset();
         std::string why;
         if (!target->state || !target->state->supported(&why)) { std::cout << "ChainManager: " << why << ".\n"; return; }
         if (thinning < 1) { std::cout << "ChainManager: thinning must be at least 1.\n"; return; }
@@ -1163,7 +1283,13 @@ protected:
             for (size_t i = 0; i < n; ++i)
                 std::cout << "Initialized chain " << i << " with true loglikelihood = " << ll[2 * i] + ll[2 * i + 1] << "\n";
         }
-        be->run(R, n, flat.data(), ss.data(), 1, nSteps, 0, nAdjust, thinning);
+        /* the manager's chains: recordSamples = false (mcmc.h:1490,1530), computeMean at its default
+         * false (mcmc.h:990), each a fresh MetropolisChain(tar, i+1) seeding rnd(0, i+1) (mcmc.h:1487,1527) */
+        RunOptions opt;
+        opt.recordSamples = recordInitialConditions;
+        opt.computeMean = false;
+        be->run(R, n, flat.data(), ss.data(), 1, nSteps, 0, nAdjust, thinning, opt);
+        lastBackend = std::move(be);
         last_diagnostics = R.diagnostics;
         nRun = n;
         std::cout << "Chain runs completed." << std::endl << std::endl;

@@ -172,9 +172,11 @@ PYBIND11_MODULE(mcmc, m) {
         })
         .def("saved_sample", [](const ChainManager& c, int s) {
             py::array_t<Float> a({c.n_chains(), (size_t)c.n_dim()});
-            std::copy(c.saved_sample(s).begin(), c.saved_sample(s).end(), a.mutable_data());
+            const std::vector<Float> pts = c.saved_sample(s);
+            std::copy(pts.begin(), pts.end(), a.mutable_data());
             return a;
         })
+        .def_readwrite("recordInitialConditions", &ChainManager::recordInitialConditions)
         .def_readwrite("stepsizes", &ChainManager::stepsizes)
         .def_readonly("last_diagnostics", &ChainManager::last_diagnostics);
 }

@@ -668,8 +668,7 @@ static int toy_run(int dimx, toy_eval_fn ev, toy_prop_fn pr, const void* ud, dou
     if (stepsize_out) *stepsize_out = sf;
     if (n_accept_out) *n_accept_out = nAccept;
     if (mean_out) {                                                 /* mcmc.h:1133-1134 */
-        const int cnt = nAdjust + nSamples - nBurnin;
-        const double f = cnt != 0 ? 1.0 / (double)cnt : 1.0;
+        const double f = 1.0 / (double)(nAdjust + nSamples - nBurnin);
         for (int k = 0; k < dimx + (with_max ? 1 : 0); ++k) mean_out[k] = mean[k] * f;
     }
     return n_saved;

@@ -450,14 +450,16 @@ def test_diagnostics_vector(R11, R10):
 
 
 # ------------------------------------------- full-size properties (BASELINE configs) ----
-def test_full_size_batch_independence_and_determinism(R11, R10):
-    """BASELINE configs[2] shape (365-day series, dim 358) at 16384 chains: the oracle is too
-    slow to follow every chain, so use size-independent properties: (1) chain i's trajectory
-    does not depend on which other chains share its wave/batch, (2) a repeat run is
-    bit-identical, (3) the first chains equal the oracle."""
+@pytest.mark.parametrize("n", [16384, 65536, 131072])
+def test_full_size_batch_independence_and_determinism(R11, R10, n):
+    """BASELINE configs[2] shape (365-day series, dim 358) at 16384 chains, at the headline's 65536
+    (1024 waves = one per SIMD, the launch shape bench.py times) and at 131072 (the per-GPU share of
+    configs[4]; twice the chip's worth of tiles): the oracle is too slow to follow every chain, so use
+    size-independent properties: (1) chain i's trajectory does not depend on which other chains share
+    its wave/batch, (2) a repeat run is bit-identical, (3) the first and the last chain equal the
+    oracle."""
     cfg = make_cfg(365, R11, contract=1)
     assert cfg["size"] == 465 and cfg["dim"] == 358
-    n = 16384
     xs = H.perturb_ics(CC.initial_params(cfg), n, 0.01)
     big = H.CovidSampler(cfg, R10)
     big.set_chains(xs, first_chain_id=1)
@@ -465,7 +467,7 @@ def test_full_size_batch_independence_and_determinism(R11, R10):
     P, LL, RNG, ACC = _state(big)
     assert np.all(np.isfinite(LL))
     # (1) a scattered subset run alone, with the same ids
-    idx = np.array([0, 1, 63, 64, 4097, 9999, n - 1])
+    idx = np.array([0, 1, 63, 64, 4097, 9999, n // 2 + 77, n - 65, n - 1])
     sub = H.CovidSampler(cfg, R10)
     sub.set_chains(xs[idx], chain_ids=idx + 1)
     sub.step(3, 1.0, True)
@@ -486,6 +488,48 @@ def test_full_size_batch_independence_and_determinism(R11, R10):
     assert np.all(RNG[:, 1] == (2 * (np.arange(n, dtype=np.uint64) + 1) + 1))
     big.close()
     sub.close()
+
+
+def test_set_state_resumes_chains_in_a_new_context(R11, R10):
+    """Checkpoint / resume across contexts (mcmc_hip_set_state): chains advanced in one context, their
+    whole state read out (params, step sizes, rng, loglike, mean, accept counts) and planted in a fresh
+    context, go on exactly like the chains that never left -- the second run()'s loglikes, samples,
+    mean and end state are bit-identical."""
+    cfg = make_cfg(40, R11, contract=1, **SMALL)
+    xs = perturbed(cfg, 70, 0.05)
+    stay = H.CovidSampler(cfg, R10)
+    stay.set_chains(xs, first_chain_id=1)
+    stay.run(15, 0, 2, 3, record_samples=True, compute_mean=True)
+    saved = dict(params=stay.params(), ss=stay.stepsizes(), rng=stay.rng_state(), ll=stay.loglike(), mean=stay.mean(),
+                 acc=stay.accept_counts())
+    stay.run(11, 2, 1, 2, record_samples=True, compute_mean=True)
+    moved = H.CovidSampler(cfg, R10)
+    moved.set_chains(saved["params"], stepsizes=saved["ss"], first_chain_id=1000)      # ids do not matter once the rng is planted
+    moved.set_state(rng_state=saved["rng"], loglike=saved["ll"], mean=saved["mean"], accept_counts=saved["acc"])
+    assert np.array_equal(moved.rng_state(), saved["rng"]) and np.array_equal(moved.loglike(), saved["ll"])
+    assert np.array_equal(moved.accept_counts(), saved["acc"]) and np.array_equal(moved.mean(), saved["mean"])
+    moved.run(11, 2, 1, 2, record_samples=True, compute_mean=True)
+    for a, b in zip(_state(stay), _state(moved)):
+        assert np.array_equal(a, b)
+    assert np.array_equal(stay.loglikes(), moved.loglikes()) and np.array_equal(stay.mean(), moved.mean())
+    assert np.array_equal(stay.stepsizes(), moved.stepsizes())
+    for c in (0, 63, 64, 69):
+        assert np.array_equal(stay.samples(c), moved.samples(c))
+    # the oracle chain run twice is the same continued chain
+    m = O.Model(cfg, R11, contract=1)
+    tgt = O.make_target("temp", 1.0)
+    oc = O.OracleChain(m, 1, xs[0])
+    oc.run(tgt, 15, 0, 2, 3)
+    ll2, s2, _ = oc.run(tgt, 11, 2, 1, 2)
+    assert np.array_equal(moved.loglikes()[0], ll2) and np.array_equal(moved.samples(0), s2)
+    # only rng given: the rest keeps what set_chains derived; a bad increment is refused
+    moved.set_chains(saved["params"], stepsizes=saved["ss"], first_chain_id=1)
+    moved.set_state(rng_state=saved["rng"])
+    assert np.array_equal(moved.loglike(), saved["ll"])                 # the evaluation is deterministic
+    bad = saved["rng"].copy(); bad[3, 1] &= ~np.uint64(1)
+    with pytest.raises(H.McmcHipError, match="odd"):
+        moved.set_state(rng_state=bad)
+    stay.close(); moved.close()
 
 
 def test_pair_count_is_the_survey_work_unit(R11, R10):

@@ -68,6 +68,8 @@ def test_chain_run_equals_oracle_chain(cooling):
     data, p, ds, state, target, cfg, m, tgt = _setup(T=2.0, cooling=cooling)
     x0 = CC.initial_params(cfg)
     chain = mcmc.Chain(target, 0)                      # id 0 like test.cpp:36
+    assert chain.computeMean is False                  # mcmc.h:990
+    chain.computeMean = True
     chain.run(60, 4, 3, 5)
     oc = O.OracleChain(m, 0, x0)
     ll, samples, mean = oc.run(tgt, 60, 4, 3, 5, record=True, mean=True)
@@ -90,6 +92,38 @@ def test_chain_run_equals_oracle_chain(cooling):
     chain.reevaluate(state, 2)
     assert np.array_equal(chain.get_loglikes(), ll[2:])
     assert np.array_equal(chain.get_samples("betaHigh"), samples[2:, -2:-1])
+
+
+def test_a_second_run_continues_the_chain():
+    """A MetropolisChain seeds `rnd` once, in its constructor (mcmc.h:994-999): run(a) then run(b) goes on
+    drawing from the same stream, APPENDS to loglikes / samples (mcmc.h:1039-1061) and keeps adding to
+    the mean it has (mcmc.h:1064-1065,1133-1134) -- the notebooks do call run repeatedly
+    (covid2.ipynb, covid3.ipynb).  Against one oracle chain run twice."""
+    data, p, ds, state, target, cfg, m, tgt = _setup(T=2.0)
+    x0 = CC.initial_params(cfg)
+    chain = mcmc.Chain(target, 7)
+    chain.computeMean = True
+    chain.run(12, 0, 2, 1)
+    chain.run(9, 0, 0, 1)
+    oc = O.OracleChain(m, 7, x0)
+    ll1, s1, mean1 = oc.run(tgt, 12, 0, 2, 1, record=True, mean=True)
+    ll2, s2, _ = oc.run(tgt, 9, 0, 0, 1, record=True, mean=False)
+    assert len(ll1) == 14 and len(ll2) == 9
+    assert np.array_equal(chain.get_loglikes(), np.concatenate([ll1, ll2]))
+    both = np.concatenate([s1, s2])
+    nB, nD = cfg["nB"], cfg["n_disc"]
+    assert np.array_equal(chain.get_samples("delay"), both[:, -1:])
+    assert np.array_equal(chain.get_samples("behavior"), both[:, :nB])
+    # the second run adds its points i > nBurnin (thinning 1: every saved point but the first) to the
+    # first run's scaled mean and scales again
+    mu = mean1.copy()
+    for pt in s2[1:]:
+        mu = mu + pt
+    mu = mu * (1.0 / 9)
+    assert np.array_equal(chain.get_mean("behavior"), mu[:nB])
+    assert np.array_equal(chain.get_mean("delay"), mu[-1:])
+    assert ds.getCoords("delay") == [oc.x[-1]] and ds.stepsizeCorrectionFac == oc.c.stepsize
+    assert state.loglike() == oc.ll[0] + oc.ll[1]
 
 
 def test_fast_mode_through_the_module():
@@ -192,6 +226,18 @@ def test_chain_manager_runs_all_chains_in_one_batch(tmp_path, monkeypatch):
     assert cm.stepsizes[0] == oc0.c.stepsize          # stepsizes = chains[0]'s, mcmc.h:1550
     with pytest.raises(IndexError):
         cm.get_chain(7)
+    # the saved points stay on the device and come over on request: point 1 of every chain
+    pts = cm.saved_sample(1)
+    oc3 = O.OracleChain(m, 4, x0)
+    assert pts.shape == (5, cfg["dim"]) and np.array_equal(pts[3], oc3.run(tgt, 30, 0, 2, 3, record=True)[1][1])
+    # recordInitialConditions = False: the log-likelihood trace only
+    lean = mcmc.ChainManager(target, 5)
+    lean.recordInitialConditions = False
+    lean.run_all(30, 2, 3, 4)
+    assert np.array_equal(lean.get_chain(3).get_loglikes(), cm.get_chain(3).get_loglikes())
+    assert np.array_equal(lean.all_final_params(), cm.all_final_params())
+    with pytest.raises(IndexError):
+        lean.saved_sample(0)
     # samples are available after reevaluate_all (run_all records only the points, mcmc.h:1490)
     monkeypatch.chdir(tmp_path)
     cm.reevaluate_all(state, 1, True, True, 1)
