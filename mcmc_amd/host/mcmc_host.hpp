@@ -503,6 +503,8 @@ public:
         hip_check(mcmc_hip_get_loglike(eng.ctx, R.fll.data()), "mcmc_hip_get_loglike");
         hip_check(mcmc_hip_get_stepsizes(eng.ctx, R.fss.data()), "mcmc_hip_get_stepsizes");
         hip_check(mcmc_hip_get_accept_counts(eng.ctx, R.acc.data()), "mcmc_hip_get_accept_counts");
+        R.rng.assign(n * 2, 0);
+        hip_check(mcmc_hip_get_rng_state(eng.ctx, R.rng.data()), "mcmc_hip_get_rng_state");
         rungs.assign(n, 0); swapAcc.assign(K - 1, 0); swapProp.assign(K - 1, 0);
         hip_check(mcmc_hip_get_rungs(eng.ctx, rungs.data()), "mcmc_hip_get_rungs");
         hip_check(mcmc_hip_get_swap_counts(eng.ctx, swapAcc.data(), swapProp.data()), "mcmc_hip_get_swap_counts");
@@ -1251,7 +1253,7 @@ protected:
         c.recordSamples = false;
         c.weight = chainICs[i].second;
         c.rec.take(R, i, *lastBackend);
-        c.rnd.state = R.rng[2 * i]; c.rnd.inc = R.rng[2 * i + 1];
+        if (R.rng.size() >= 2 * (i + 1)) { c.rnd.state = R.rng[2 * i]; c.rnd.inc = R.rng[2 * i + 1]; }
         c.rec.apply_to(*tar->state);
         return chains.emplace(i, std::move(c)).first->second;
     }
