@@ -12,6 +12,7 @@ int main(int argc, char** argv) {
         auto s = std::make_shared<MyState>();                 // init() evaluates on the device
         t->set_posterior(s);
         MetropolisChain chain(t, 0);
+        chain.computeMean = true;                             // false by default, mcmc.h:990
         chain.run(nSamples, 10, 500, 5);                      // test.cpp:38
         size_t len = 0;
         std::vector<Float> pos = chain.get_samples("position", &len);

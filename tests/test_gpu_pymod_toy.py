@@ -30,6 +30,7 @@ def test_cli_config_through_the_module():
     assert s.loglike() == -11.0 and s.get_all() == {"position": [1, 1, 1], "max": [1]}
     t.set_posterior(s)
     chain = mcmc.Chain(t, 0)
+    chain.computeMean = True                           # default false, mcmc.h:990
     chain.run(100000, 10, 500, 5)
     ll, smp, sf, nacc, mean = O.mylike1_run(0, 100000, 10, 500, 5, with_mean=True)
     assert np.array_equal(chain.get_loglikes(), ll)
@@ -57,12 +58,33 @@ def test_four_gaussians_generator_chain_and_reevaluate():
     lh, s, t = _four_gaussians(10)                     # test2.ipynb cell 2
     assert s.loglike() == _fg_ll([0.0, 0.0])[0]
     c = mcmc.Chain(t, 0)
+    c.computeMean = True
     c.run(5000, 500, 200, 10)                          # cell 3, smaller
     ll, smp, sf, nacc, mean = O.fourgauss_run(6.0, 10.0, 0, [0.0, 0.0], 5000, 500, 200, 10, with_mean=True)
     assert np.array_equal(c.get_loglikes(), ll) and np.array_equal(c.get_samples("pos"), smp)
     assert np.array_equal(c.get_mean("pos"), mean) and lh.stepsizeCorrectionFac == sf
     c.reevaluate(s, 100)                               # cell 4
     assert np.array_equal(c.get_loglikes(), ll[100:]) and np.array_equal(c.get_samples("pos"), smp[100:])
+
+
+def test_toy_chain_continues_over_two_runs():
+    """rnd is seeded once per chain (mcmc.h:994-999): without an adjust phase, under a constant beta and with
+    thinning 1, run(300) followed by run(200) IS run(500) -- same stream, points appended."""
+    lh1, s1, t1 = _four_gaussians(10)
+    a = mcmc.Chain(t1, 4)
+    a.run(300, 0, 0, 1)
+    a.run(200, 0, 0, 1)
+    lh2, s2, t2 = _four_gaussians(10)
+    b = mcmc.Chain(t2, 4)
+    b.run(500, 0, 0, 1)
+    assert np.array_equal(a.get_samples("pos"), b.get_samples("pos")) and len(a.get_loglikes()) == 500
+    assert np.array_equal(a.get_loglikes(), b.get_loglikes())
+    assert s1.get_all() == s2.get_all()
+    # and a fresh chain object with the same id starts the stream again
+    lh3, s3, t3 = _four_gaussians(10)
+    c = mcmc.Chain(t3, 4)
+    c.run(300, 0, 0, 1)
+    assert np.array_equal(c.get_samples("pos"), b.get_samples("pos")[:300])
 
 
 def _bootstrap_picks(r, w_log, n):
