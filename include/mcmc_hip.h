@@ -189,6 +189,20 @@ int mcmc_hip_eval(mcmc_hip_ctx* ctx, int64_t n, const double* params /*[n][dim]*
  * only on request (the reference's compute_derived_late idea, mcmc.h:100-104). */
 int mcmc_hip_derive(mcmc_hip_ctx* ctx, int64_t n, const double* params, double* curves_out);
 
+/* mcmc_hip_eval for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE (its chains
+ * allocate freely, e.g. copy() at covid.h:501): this variant exists for callers that must not
+ * reach hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid it.
+ * Same kernels and results as mcmc_hip_eval (bit for bit), but params_dev [n][dim] and ll_out_dev
+ * [n][2] are DEVICE pointers on the context's GPU, and the kernels' scratch (tiled parameters,
+ * per-lane histories, weighted deaths, results) is a file-scope device array of 16 MiB that every
+ * GPU the library runs on holds until the process ends.  The call allocates and frees nothing;
+ * it returns after its kernels have finished (it synchronises the context's stream).  n is
+ * limited by that array: mcmc_hip_eval_static_max(ctx) vectors for this model (960 at 365 data
+ * days); a larger n is rejected with MCMC_HIP_EINVAL.  Every call on one GPU shares that GPU's
+ * array, from any context: calls that overlap on one GPU race -- serialise them. */
+int mcmc_hip_eval_static(mcmc_hip_ctx* ctx, int64_t n, const double* params_dev, double* ll_out_dev);
+int64_t mcmc_hip_eval_static_max(const mcmc_hip_ctx* ctx);
+
 /* Cross-chain diagnostics of the current state, reduced on the device with wavefront
  * shuffle reductions: out[0]=sum of run()'s nAccept, out[1]=number of Target::step calls
  * per chain since set_chains/run start, out[2]=sum loglike, out[3]=sum loglike^2,

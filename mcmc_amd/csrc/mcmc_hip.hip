@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <exception>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -28,6 +29,16 @@
 #ifndef MCMC_T_DERIVE
 #define MCMC_T_DERIVE 4    /* the derive kernel is not a hot path: small block, short compile */
 #endif
+
+/* ---- the one entry point that allocates nothing (mcmc_hip_eval_static) -----------------------
+ * Its kernels' scratch -- the tiled copy of the parameter vectors, both per-lane histories, the
+ * weighted-deaths rows and the result rows, everything mcmc_hip_eval hipMallocs per call -- lives
+ * in this file-scope device array.  Every GPU the library runs on holds its own copy, at its own
+ * address, until the process ends.  In host code the array's NAME is only a handle: the address
+ * kernels and memsets may use is the one hipGetSymbolAddress returns, fetched once per device in
+ * mcmc_hip_create (static_scratch_for) with that device current, and only that pointer is used. */
+#define MCMC_STATIC_SCRATCH_BYTES (16u << 20)
+static __device__ __align__(256) double g_static_scratch[MCMC_STATIC_SCRATCH_BYTES / sizeof(double)];
 
 namespace {
 
@@ -81,6 +92,7 @@ struct mcmc_hip_ctx {
     std::vector<int32_t> discDays;
     std::vector<uint8_t> discFixed;
     int device = 0, nCU = 0;
+    double* staticScratch = nullptr;    /* this device's g_static_scratch (mcmc_hip_eval_static) */
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int size = 0, nB = 0, dim = 0, simDays = 0, simPad = 0, nLag = 0, tabRows = 0, histRows = 0;
@@ -231,6 +243,23 @@ struct Trajectories {
 };
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+/* device address of g_static_scratch on `device` (which must be current): asked once per device */
+constexpr int kMaxDevices = 64;
+double* g_scratch_of_device[kMaxDevices];
+std::mutex g_scratch_mu;
+int static_scratch_for(int device, double** out) {
+    if (device < 0 || device >= kMaxDevices) return fail(MCMC_HIP_EINVAL, "device ordinal %d beyond %d", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_of_device[device]) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch)));
+        if (!p) return fail(MCMC_HIP_EHIP, "hipGetSymbolAddress returned a null address for the static scratch");
+        g_scratch_of_device[device] = (double*)p;
+    }
+    *out = g_scratch_of_device[device];
+    return 0;
+}
 
 double target_beta(const mcmc_covid_config& c, double time) {
     switch (c.target_kind) {
@@ -416,6 +445,7 @@ static int init_ctx(mcmc_hip_ctx* c, const mcmc_covid_config* cfg, int device) {
     c->cfg.disc_fixed = c->discFixed.data();
     c->device = device;
     HIP_TRY(hipDeviceGetAttribute(&c->nCU, hipDeviceAttributeMultiprocessorCount, device));
+    if (int r = static_scratch_for(device, &c->staticScratch)) return r;      /* hipSetDevice(device) was just made */
     c->size = cfg->max_delay + cfg->n_predict + cfg->n_data;          /* covid.h:297 */
     c->nB = cfg->n_data - cfg->fix_behavior_in_advance;               /* covid.h:299 */
     c->dim = c->nB + cfg->n_disc + 3;
@@ -952,6 +982,67 @@ int mcmc_hip_eval(mcmc_hip_ctx* c, int64_t n, const double* params, double* ll_o
 } MCMC_ABI_GUARD
 int mcmc_hip_derive(mcmc_hip_ctx* c, int64_t n, const double* params, double* curves_out) try {
     return with_external(c, n, params, true, curves_out);
+} MCMC_ABI_GUARD
+
+/* rows of 64-lane doubles one tile of mcmc_hip_eval_static needs in the static scratch */
+static size_t static_rows_per_tile(const mcmc_hip_ctx* c) {
+    return (size_t)c->dim + 2 * (size_t)c->histRows + 2 * (size_t)c->cfg.n_data + 2;
+}
+
+int64_t mcmc_hip_eval_static_max(const mcmc_hip_ctx* c) {
+    if (!c) return MCMC_HIP_EINVAL;
+    const size_t tiles = (size_t)MCMC_STATIC_SCRATCH_BYTES / (static_rows_per_tile(c) * MCMC_WAVE * sizeof(double));
+    return (int64_t)(tiles * MCMC_WAVE);
+}
+
+int mcmc_hip_eval_static(mcmc_hip_ctx* c, int64_t n, const double* params_dev, double* ll_out_dev) try {
+    if (int r = check_ctx(c)) return r;
+    if (!c->haveTables || !c->haveData) return fail(MCMC_HIP_ESTATE, "call set_tables and set_data first");
+    if (n < 1 || !params_dev || !ll_out_dev) return fail(MCMC_HIP_EINVAL, "need n >= 1, device params and a device output buffer");
+    const int64_t nMax = mcmc_hip_eval_static_max(c);
+    if (n > nMax)
+        return fail(MCMC_HIP_EINVAL, "eval_static: %lld parameter vectors exceed the static scratch (%u bytes hold at most %lld "
+                    "vectors of this model); use mcmc_hip_eval", (long long)n, (unsigned)MCMC_STATIC_SCRATCH_BYTES, (long long)nMax);
+    if (!c->staticScratch) return fail(MCMC_HIP_ESTATE, "eval_static: no static scratch address for this device");
+    HIP_TRY(hipSetDevice(c->device));
+    const long long nP = (n + MCMC_WAVE - 1) / MCMC_WAVE * MCMC_WAVE;
+    const int dim = c->dim;
+    /* carve this device's array: [soa | hn | he | d1s | res], each tile-major for nP lanes; the
+     * array keeps the last call's contents, so everything this call uses starts at zero, as the
+     * freshly allocated buffers of mcmc_hip_eval do */
+    double* base = c->staticScratch;
+    double* soa = base;
+    double* hn = soa + (size_t)dim * nP;
+    double* he = hn + (size_t)c->histRows * nP;
+    double* d1s = he + (size_t)c->histRows * nP;
+    double* res = d1s + (size_t)2 * c->cfg.n_data * nP;
+    const size_t used = static_rows_per_tile(c) * (size_t)nP * sizeof(double);
+    HIP_TRY(hipMemsetAsync(base, 0, used, c->stream));
+    ChainState S{};
+    S.hn = hn; S.he = he; S.d1s = d1s; S.histRows = c->histRows; S.nTiles = (int)(nP / MCMC_WAVE);
+    S.dim = dim; S.nChains = n;
+    mcmc_hip_ctx tmp;                      /* launch geometry only: borrows the stream, owns nothing */
+    tmp.cfg = c->cfg; tmp.device = c->device; tmp.nCU = c->nCU; tmp.stream = c->stream; tmp.M = c->M;
+    tmp.nTiles = S.nTiles; tmp.nP = nP; tmp.nChains = n; tmp.dim = dim;
+    const unsigned tb = 256, tg = (unsigned)((nP + tb - 1) / tb);
+    hipLaunchKernelGGL(tile_in_kernel<double>, dim3(tg), dim3(tb), 0, c->stream, params_dev, soa, (long long)n, dim, nP);
+    int rc = 0;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) rc = fail(MCMC_HIP_EHIP, "tile_in launch failed: %s", hipGetErrorString(e));
+    if (!rc) {
+        if (c->precision == MCMC_HIP_PRECISION_F32_MODEL) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true, 1>, false, MCMC_T, tmp.M, S, (const double*)soa, res);
+        else if (c->cfg.contract) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true>, false, MCMC_T, tmp.M, S, (const double*)soa, res);
+        else rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, false>, false, MCMC_T, tmp.M, S, (const double*)soa, res);
+    }
+    if (!rc) {
+        const unsigned og = (unsigned)((n + tb - 1) / tb);
+        hipLaunchKernelGGL(tile_out_kernel<double>, dim3(og), dim3(tb), 0, c->stream, (const double*)res, ll_out_dev, (long long)n, 2);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(MCMC_HIP_EHIP, "eval_static: kernel failed: %s", hipGetErrorString(e));
+    }
+    tmp.stream = nullptr;                  /* borrowed */
+    return rc;
 } MCMC_ABI_GUARD
 
 int mcmc_hip_diagnostics(mcmc_hip_ctx* c, double* out) try {

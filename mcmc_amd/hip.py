@@ -29,7 +29,7 @@ SYMBOLS = [
     "mcmc_hip_get_accept_counts", "mcmc_hip_get_rng_state", "mcmc_hip_get_loglikes",
     "mcmc_hip_get_samples", "mcmc_hip_get_sample_all", "mcmc_hip_get_mean", "mcmc_hip_eval",
     "mcmc_hip_derive", "mcmc_hip_diagnostics", "mcmc_hip_last_timing", "mcmc_hip_pair_count",
-    "mcmc_hip_executed_pair_count",
+    "mcmc_hip_executed_pair_count", "mcmc_hip_eval_static", "mcmc_hip_eval_static_max",
     "mcmc_hip_debug_phase_cycles", "mcmc_hip_set_ladder", "mcmc_hip_swap", "mcmc_hip_run_tempered",
     "mcmc_hip_get_rungs", "mcmc_hip_get_swap_counts", "mcmc_hip_toy_dim", "mcmc_hip_toy_n_out", "mcmc_hip_toy_eval", "mcmc_hip_toy_run",
 ]
@@ -99,6 +99,9 @@ def lib():
     L.mcmc_hip_get_sample_all.argtypes = [vp, C.c_int32, dp]
     L.mcmc_hip_eval.argtypes = [vp, C.c_int64, dp, dp]
     L.mcmc_hip_derive.argtypes = [vp, C.c_int64, dp, dp]
+    L.mcmc_hip_eval_static.argtypes = [vp, C.c_int64, C.c_void_p, C.c_void_p]      # DEVICE pointers
+    L.mcmc_hip_eval_static_max.argtypes = [vp]
+    L.mcmc_hip_eval_static_max.restype = C.c_int64
     L.mcmc_hip_last_timing.argtypes = [vp, dp, dp, dp, C.POINTER(C.c_int64)]
     L.mcmc_hip_pair_count.argtypes = [vp, dp, C.c_int32]
     L.mcmc_hip_executed_pair_count.argtypes = [vp, dp, C.c_int32]
@@ -333,6 +336,13 @@ class CovidSampler:
         out = np.zeros((params.shape[0], 2))
         _check(lib().mcmc_hip_eval(self._h, params.shape[0], _dp(params), _dp(out)))
         return out
+
+    def eval_static(self, n, params_dev_ptr, ll_out_dev_ptr):
+        """mcmc_hip_eval_static: device pointers (integers), no allocation inside the library."""
+        _check(lib().mcmc_hip_eval_static(self._h, n, C.c_void_p(params_dev_ptr), C.c_void_p(ll_out_dev_ptr)))
+
+    def eval_static_max(self):
+        return int(lib().mcmc_hip_eval_static_max(self._h))
 
     def derive(self, params):
         params = np.ascontiguousarray(np.atleast_2d(params), dtype=np.float64)
