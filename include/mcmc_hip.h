@@ -258,9 +258,13 @@ int mcmc_hip_get_swap_counts(mcmc_hip_ctx* ctx, int64_t* accepted, int64_t* prop
  * mcmc.h:994-1003): rng_state [n][2] non-NULL = start from these pcg32 (state, inc) instead of
  * seeding, and receive the end state; mean_continue = 1: mean_out holds the previous run's mean
  * on entry and the run adds to it (mcmc.h:1064-1065,1133-1134). */
-enum mcmc_toy_kind { MCMC_TOY_MYLIKE1 = 0, MCMC_TOY_FOURGAUSS = 1 };
-int mcmc_hip_toy_dim(int32_t kind);                                   /* 3, 2 */
-int mcmc_hip_toy_n_out(int32_t kind);                                 /* 4, 2 */
+/* MCMC_TOY_ROSENBROCK (EXTENSION: BASELINE.json configs[0] names a Rosenbrock target, the reference
+ * has none) follows FourGaussians' pattern (test.h:69-136): coordinate "pos" (x, y), step
+ * pos[k] += stepsizeCorrectionFac * (nextFloat() - 0.5) without bounds, and
+ * loglike = -((1 - x)^2 + difficulty * (y - x^2)^2) / 20; difficulty = 100 is the usual density. */
+enum mcmc_toy_kind { MCMC_TOY_MYLIKE1 = 0, MCMC_TOY_FOURGAUSS = 1, MCMC_TOY_ROSENBROCK = 2 };
+int mcmc_hip_toy_dim(int32_t kind);                                   /* 3, 2, 2 */
+int mcmc_hip_toy_n_out(int32_t kind);                                 /* 4, 2, 2 */
 int mcmc_hip_toy_eval(int device, int32_t kind, double difficulty, int64_t n, const double* x, double* ll_out);
 int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target_kind, double target_T,
                      double target_slope, double target_Tinit, int64_t n_chains, const uint64_t* chain_ids,

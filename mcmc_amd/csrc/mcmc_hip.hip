@@ -1103,8 +1103,8 @@ int mcmc_hip_executed_pair_count(mcmc_hip_ctx* c, double* pairs_out, int32_t res
 } MCMC_ABI_GUARD
 
 /* ------------------------------------------------------------------ toy targets ---- */
-static int toy_dim(int kind) { return kind == MCMC_TOY_MYLIKE1 ? 3 : kind == MCMC_TOY_FOURGAUSS ? 2 : -1; }
-static int toy_n_out(int kind) { return kind == MCMC_TOY_MYLIKE1 ? 4 : kind == MCMC_TOY_FOURGAUSS ? 2 : -1; }
+static int toy_dim(int kind) { return kind == MCMC_TOY_MYLIKE1 ? 3 : (kind == MCMC_TOY_FOURGAUSS || kind == MCMC_TOY_ROSENBROCK) ? 2 : -1; }
+static int toy_n_out(int kind) { return kind == MCMC_TOY_MYLIKE1 ? 4 : (kind == MCMC_TOY_FOURGAUSS || kind == MCMC_TOY_ROSENBROCK) ? 2 : -1; }
 
 int mcmc_hip_toy_dim(int32_t kind) try {
     const int d = toy_dim(kind);
@@ -1138,6 +1138,7 @@ int mcmc_hip_toy_eval(int device, int32_t kind, double difficulty, int64_t n, co
     HIP_TRY(hipMemcpy(dx.p, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice));
     const unsigned grid = (unsigned)((n + 255) / 256);
     if (kind == MCMC_TOY_MYLIKE1) hipLaunchKernelGGL(toy_eval_kernel<TOY_MYLIKE1>, dim3(grid), dim3(256), 0, 0, (const double*)dx.p, dl.p, (long long)n, difficulty);
+    else if (kind == MCMC_TOY_ROSENBROCK) hipLaunchKernelGGL(toy_eval_kernel<TOY_ROSENBROCK>, dim3(grid), dim3(256), 0, 0, (const double*)dx.p, dl.p, (long long)n, difficulty);
     else hipLaunchKernelGGL(toy_eval_kernel<TOY_FOURGAUSS>, dim3(grid), dim3(256), 0, 0, (const double*)dx.p, dl.p, (long long)n, difficulty);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(ll_out, dl.p, n * sizeof(double), hipMemcpyDeviceToHost));
@@ -1201,6 +1202,9 @@ int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target
     const unsigned grid = (unsigned)((n + 255) / 256);
     if (kind == MCMC_TOY_MYLIKE1)
         hipLaunchKernelGGL(toy_run_kernel<TOY_MYLIKE1>, dim3(grid), dim3(256), 0, 0, dx.p, dss.p, (const uint64_t*)dids.p, (long long)n,
+                           difficulty, (const double*)dbeta.p, nSamples, nBurnin, nAdjust, thinning, dll.p, dsamp.p, dmean.p, dacc.p, drng.p, (int)mean_continue);
+    else if (kind == MCMC_TOY_ROSENBROCK)
+        hipLaunchKernelGGL(toy_run_kernel<TOY_ROSENBROCK>, dim3(grid), dim3(256), 0, 0, dx.p, dss.p, (const uint64_t*)dids.p, (long long)n,
                            difficulty, (const double*)dbeta.p, nSamples, nBurnin, nAdjust, thinning, dll.p, dsamp.p, dmean.p, dacc.p, drng.p, (int)mean_continue);
     else
         hipLaunchKernelGGL(toy_run_kernel<TOY_FOURGAUSS>, dim3(grid), dim3(256), 0, 0, dx.p, dss.p, (const uint64_t*)dids.p, (long long)n,

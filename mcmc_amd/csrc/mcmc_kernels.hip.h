@@ -1411,8 +1411,14 @@ __global__ __launch_bounds__(256) void ladder_swap_kernel(ChainState S, int hasP
 /* ------------------------------------------------------------------ toy targets ---- */
 /* MyLike1 (test.h:14-67) and FourGaussians (test.h:69-136) under MetropolisChain::run
  * (mcmc.h:1005-1138) with a one-likelihood State: one chain per lane, the whole run in one
- * launch.  Chain-flat layouts: x [dim][n], recLL [slot][n], recS [slot][dim][n]. */
-enum { TOY_MYLIKE1 = 0, TOY_FOURGAUSS = 1 };
+ * launch.  Chain-flat layouts: x [dim][n], recLL [slot][n], recS [slot][dim][n].
+ * TOY_ROSENBROCK (EXTENSION, BASELINE configs[0] "Gaussian/Rosenbrock"; the reference has no such
+ * target) follows FourGaussians' pattern -- one 2-D coordinate "pos", a random-walk step of
+ * stepsizeCorrectionFac * (nextFloat() - 0.5) per component (test.h:105), no bounds:
+ *     loglike = -((1 - x)^2 + difficulty * (y - x^2)^2) / 20
+ * (difficulty = 100: the Rosenbrock density of Goodman & Weare 2010; x ~ N(1, 10),
+ * y | x ~ N(x^2, 10 / difficulty)). */
+enum { TOY_MYLIKE1 = 0, TOY_FOURGAUSS = 1, TOY_ROSENBROCK = 2 };
 
 template <int KIND>
 __device__ __forceinline__ double toy_loglike(const double (&x)[3], double difficulty) {
@@ -1424,6 +1430,9 @@ __device__ __forceinline__ double toy_loglike(const double (&x)[3], double diffi
 #pragma unroll
             for (int j = 0; j < 3; ++j) loglike -= (dp[i][j] - x[j]) * (dp[i][j] - x[j]) * 0.5;
         return loglike;
+    } else if constexpr (KIND == TOY_ROSENBROCK) {
+        const double u = 1 - x[0], v = x[1] - x[0] * x[0];
+        return -(u * u + difficulty * (v * v)) / 20;
     } else {
         const double a = x[0], y = x[1];
         double loglike;
@@ -1506,6 +1515,8 @@ __global__ __launch_bounds__(256) void toy_run_kernel(double* __restrict__ x, do
             for (int k = 0; k < DIM; ++k) {
                 if constexpr (KIND == TOY_MYLIKE1) {
                     prop[k] = cur[k] + 10 * sf * ((double)rnd.next_float() - 0.5);            /* test.h:50 */
+                } else if constexpr (KIND == TOY_ROSENBROCK) {
+                    prop[k] = cur[k] + sf * ((double)rnd.next_float() - 0.5);                 /* unbounded */
                 } else {
                     prop[k] = cur[k] + sf * ((double)rnd.next_float() - 0.5);                 /* test.h:105 */
                     prop[k] = bound_reflect(prop[k], -5.0, 5.0);

@@ -149,7 +149,7 @@ def perturb_ics(x0, n_chains, a=0.01, initstate=0, initseq=0):
     return out
 
 
-TOY = {"mylike1": 0, "fourgauss": 1}
+TOY = {"mylike1": 0, "fourgauss": 1, "rosenbrock": 2}
 
 
 def toy_eval(kind, x, difficulty=1.0, device=0):

@@ -333,6 +333,22 @@ public:
     std::shared_ptr<SubspaceState> copy() const override { return std::make_shared<FourGaussians>(*this); }
 };
 
+/* EXTENSION (BASELINE configs[0] names a Rosenbrock target; the reference has none): FourGaussians'
+ * pattern with loglike = -((1-x)^2 + difficulty (y-x^2)^2) / 20 and an unbounded random-walk step. */
+class Rosenbrock : public ToyLikelihood {
+public:
+    Rosenbrock(Float difficulty = 100) : ToyLikelihood({"pos"}, MCMC_TOY_ROSENBROCK, difficulty) { setCoords({{0, 0}}); }
+    std::vector<Float> sampleInitialConditions(pcg32& rnd) override {    /* as test.h:116-123 */
+        std::vector<Float> ret = {-5 + 10 * rnd.nextDouble()};
+        ret.push_back(-5 + 10 * rnd.nextDouble());
+        unpack(ret.data());
+        return ret;
+    }
+    std::vector<Float> getInitialConditions() override { return coords[0]; }
+    void setInitialConditions(const std::vector<Float>& ics) override { if (ics.size() >= 2) unpack(ics.data()); }
+    std::shared_ptr<SubspaceState> copy() const override { return std::make_shared<Rosenbrock>(*this); }
+};
+
 /* ---------------------------------------------------------------- device engine ---- */
 enum class TargetKind { Plain = MCMC_TARGET_PLAIN, Temp = MCMC_TARGET_TEMP, Cooling = MCMC_TARGET_COOLING };
 struct TargetSpec { TargetKind kind = TargetKind::Plain; Float T = 1, slope = 0, Tinit = 1; };
@@ -580,7 +596,7 @@ private:
 /* ------------------------------------------------------------------------- State ---- */
 /* mcmc.h:241-700, restricted to the compositions the device path runs:
  *     [ DiseaseSpread ],  [ DiseaseSpread, SmoothnessPrior("behavior", Ls, L) ],
- *     [ MyLike1 ],  [ FourGaussians(difficulty) ] */
+ *     [ MyLike1 ],  [ FourGaussians(difficulty) ],  [ Rosenbrock(difficulty) ] */
 class State {
 public:
     std::vector<std::shared_ptr<SubspaceState>> state;

@@ -44,6 +44,8 @@ PYBIND11_MODULE(mcmc, m) {
         .def(py::init<>());
     py::class_<FourGaussians, SubspaceState, std::shared_ptr<FourGaussians>>(m, "FourGaussians")
         .def(py::init<Float>());
+    py::class_<Rosenbrock, SubspaceState, std::shared_ptr<Rosenbrock>>(m, "Rosenbrock")     /* extension, configs[0] */
+        .def(py::init<Float>(), py::arg("difficulty") = 100.0);
 
     py::class_<DiseaseParams>(m, "DiseaseParams")
         .def(py::init<>())

@@ -723,6 +723,28 @@ int orc_fourgauss_run(double difficulty, double T, int chain_id, const double* x
                    nAdjust, thinning, loglikes_out, samples_out, stepsize_out, n_accept_out, mean_out, 0, stepsize0);
 }
 
+/* Rosenbrock (EXTENSION, BASELINE configs[0]; no counterpart in the reference): FourGaussians'
+ * pattern (test.h:69-136) with loglike = -((1-x)^2 + difficulty (y-x^2)^2) / 20 and an unbounded
+ * random-walk step (test.h:105 without the bound() of test.h:106) */
+static double rosen_eval(const double* p, const void* ud) {
+    double difficulty = *(const double*)ud;
+    double u = 1 - p[0], v = p[1] - p[0] * p[0];
+    return -(u * u + difficulty * (v * v)) / 20;
+}
+static void rosen_prop(orc_pcg32* r, const double* x, double sf, double* xp, const void* ud) {
+    (void)ud;
+    for (int j = 0; j < 2; ++j) xp[j] = x[j] + sf * (orc_pcg32_next_float(r) - 0.5);
+}
+int orc_rosenbrock_run(double difficulty, double T, int chain_id, const double* x0, int nSamples,
+                       int nBurnin, int nAdjust, int thinning, double* loglikes_out,
+                       double* samples_out, double* stepsize_out, int* n_accept_out, double* mean_out /* [2] */,
+                       double stepsize0) {
+    double x[2] = {x0 ? x0[0] : 0.0, x0 ? x0[1] : 0.0};
+    return toy_run(2, rosen_eval, rosen_prop, &difficulty, 1 / T, chain_id, x, nSamples, nBurnin,
+                   nAdjust, thinning, loglikes_out, samples_out, stepsize_out, n_accept_out, mean_out, 0, stepsize0);
+}
+double orc_rosenbrock_eval(double difficulty, const double* x) { return rosen_eval(x, &difficulty); }
+
 /* mcmc_detmath.h entry points, exported so that tests can compare them with libm */
 double orc_det_cos(double x) { return mcmc_cos(x); }
 double orc_det_exp(double x) { return mcmc_exp(x); }

@@ -188,6 +188,13 @@ int orc_fourgauss_run(double difficulty, double T, int chain_id, const double* x
                       double* loglikes_out, double* samples_out, double* stepsize_out,
                       int* n_accept_out, double* mean_out /* [2] or NULL */, double stepsize0);
 
+/* Rosenbrock (EXTENSION, BASELINE configs[0]): see mcmc_oracle.c; same calling convention */
+int orc_rosenbrock_run(double difficulty, double T, int chain_id, const double* x0,
+                       int nSamples, int nBurnin, int nAdjust, int thinning,
+                       double* loglikes_out, double* samples_out, double* stepsize_out,
+                       int* n_accept_out, double* mean_out /* [2] or NULL */, double stepsize0);
+double orc_rosenbrock_eval(double difficulty, const double* x);
+
 /* include/mcmc_detmath.h, exported for tests */
 double orc_det_cos(double x);
 double orc_det_exp(double x);

@@ -122,6 +122,10 @@ def lib():
     L.orc_fourgauss_run.argtypes = [C.c_double, C.c_double, C.c_int, dp] + [C.c_int] * 4 + \
                                    [dp, dp, dp, C.POINTER(C.c_int), dp, C.c_double]
     L.orc_fourgauss_run.restype = C.c_int
+    L.orc_rosenbrock_run.argtypes = L.orc_fourgauss_run.argtypes
+    L.orc_rosenbrock_run.restype = C.c_int
+    L.orc_rosenbrock_eval.argtypes = [C.c_double, dp]
+    L.orc_rosenbrock_eval.restype = C.c_double
     L.orc_det_cos.argtypes = [C.c_double]
     L.orc_det_cos.restype = C.c_double
     L.orc_det_exp.argtypes = [C.c_double]
@@ -310,4 +314,13 @@ def fourgauss_run(difficulty, T, chain_id, x0, nSamples, nBurnin, nAdjust, thinn
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     lib().orc_fourgauss_run(difficulty, T, chain_id, _dp(x0), nSamples, nBurnin, nAdjust, thinning,
                             _dp(ll), _dp(s), C.byref(sf), C.byref(na), _dp(mean), stepsize)
+    return (ll, s, sf.value, na.value, mean) if with_mean else (ll, s, sf.value, na.value)
+
+
+def rosenbrock_run(difficulty, T, chain_id, x0, nSamples, nBurnin, nAdjust, thinning, with_mean=False, stepsize=1.0):
+    n = lib().orc_n_saved(nSamples, nBurnin, nAdjust, thinning)
+    ll = np.zeros(n); s = np.zeros((n, 2)); sf = C.c_double(); na = C.c_int(); mean = np.zeros(2)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    lib().orc_rosenbrock_run(difficulty, T, chain_id, _dp(x0), nSamples, nBurnin, nAdjust, thinning,
+                             _dp(ll), _dp(s), C.byref(sf), C.byref(na), _dp(mean), stepsize)
     return (ll, s, sf.value, na.value, mean) if with_mean else (ll, s, sf.value, na.value)

@@ -176,3 +176,20 @@ def test_module_reproduces_the_reference_notebook_reservoir_flow(capfd):
     capfd.readouterr()                                 # the reference's progress prints
     got = np.array([cm.saved_sample(10 * k + 1)[0] for k in range(1, 10)])
     assert np.allclose(got, g["cell8"]["chain0_pos"], rtol=0, atol=5.1e-9)
+
+
+def test_rosenbrock_through_the_module():
+    """mcmc.Rosenbrock (extension, BASELINE configs[0]) as the single likelihood of a State: Chain.run equals the
+    oracle chain bit for bit."""
+    lh = mcmc.Rosenbrock(100.0)
+    s = mcmc.State()
+    s.add(lh)
+    t = mcmc.TempTarget(1.0)
+    t.set_posterior(s)
+    assert s.loglike() == -1.0 / 20
+    c = mcmc.Chain(t, 2)
+    c.computeMean = True
+    c.run(4000, 100, 50, 7)
+    ll, smp, sf, nacc, mean = O.rosenbrock_run(100.0, 1.0, 2, [0.0, 0.0], 4000, 100, 50, 7, with_mean=True)
+    assert np.array_equal(c.get_loglikes(), ll) and np.array_equal(c.get_samples("pos"), smp)
+    assert np.array_equal(c.get_mean("pos"), mean) and lh.stepsizeCorrectionFac == sf

@@ -76,3 +76,33 @@ def test_gpu_chain_reproduces_the_reference_notebook():
     c5 = g["cell5"]
     assert np.allclose(head[:, 0], c5["x_head"], rtol=0, atol=tol) and np.allclose(head[:, 1], c5["y_head"], rtol=0, atol=tol)
     assert np.allclose(tail[:, 0], c5["x_tail"], rtol=0, atol=tol) and np.allclose(tail[:, 1], c5["y_tail"], rtol=0, atol=tol)
+
+
+def test_rosenbrock_chains_equal_the_oracle_and_the_analytic_moments():
+    """TOY_ROSENBROCK (extension, BASELINE configs[0]): bit-exact against the oracle's chains for three ids
+    under TempTarget(2) with adjust phase, burn-in, thinning and mean; batched loglike bit-exact; and the
+    moments of the target itself: x ~ N(1, 10), y | x ~ N(x^2, 10/difficulty), so E[x] = 1, Var[x] = 10,
+    E[y] = 11 -- kept by 4096 chains x 40000 steps started from exact draws (Monte-Carlo tolerance)."""
+    x0 = np.array([[0.0, 0.0], [1.5, -0.5], [-2.0, 3.0]])
+    r = H.toy_run("rosenbrock", x0, 3000, 5, 100, 10, difficulty=100.0, target="temp", T=2.0, chain_ids=[0, 5, 9])
+    for i, cid in enumerate([0, 5, 9]):
+        ll, s, sf, nacc, mean = O.rosenbrock_run(100.0, 2.0, cid, x0[i], 3000, 5, 100, 10, with_mean=True)
+        assert np.array_equal(r["loglikes"][i], ll) and np.array_equal(r["samples"][i], s)
+        assert r["stepsizes"][i] == sf and r["n_accept"][i] == nacc and np.array_equal(r["mean"][i], mean)
+    x = np.random.default_rng(3).normal(size=(500, 2)) * 3
+    L = O.lib()
+    want = np.array([L.orc_rosenbrock_eval(100.0, np.ascontiguousarray(v).ctypes.data_as(O.C.POINTER(O.C.c_double))) for v in x])
+    assert np.array_equal(H.toy_eval("rosenbrock", x, difficulty=100.0), want)
+    assert H.toy_eval("rosenbrock", [[1.0, 1.0]], difficulty=100.0)[0] == 0.0          # the mode
+    n = 4096
+    rng = np.random.default_rng(11)
+    # a random walk explores the curved ridge slowly: start from exact draws of the target and check that
+    # the sampler keeps its moments
+    xs = np.stack([1 + np.sqrt(10.0) * rng.standard_normal(n), np.zeros(n)], axis=1)
+    xs[:, 1] = xs[:, 0] ** 2 + np.sqrt(0.1) * rng.standard_normal(n)
+    big = H.toy_run("rosenbrock", xs, 40000, 10000, 500, 100, difficulty=100.0, first_chain_id=1)
+    pts = big["samples"].reshape(-1, 2)
+    got = (pts[:, 0].mean(), pts[:, 0].var(), pts[:, 1].mean(), (pts[:, 1] - pts[:, 0] ** 2).var())
+    assert abs(got[0] - 1.0) < 0.3 and abs(got[1] - 10.0) < 2.0, got
+    assert abs(got[2] - 11.0) < 2.0, got
+    assert abs(got[3] - 0.1) < 0.01, got                                 # the ridge's width

@@ -494,3 +494,27 @@ def test_faithful_copy_mode_runs_the_same_chain(R11):
     ra = O.run_chains(lean, tgt, perturbed(cfg, 3, 0.05), 1.0, 10, 0, 1, 1, n_threads=2)
     rb = O.run_chains(faithful, tgt, perturbed(cfg, 3, 0.05), 1.0, 10, 0, 1, 1, n_threads=2)
     assert np.array_equal(ra["x"], rb["x"]) and np.array_equal(ra["rng"], rb["rng"])
+
+
+def test_toy_rosenbrock_oracle_moments():
+    """the oracle's Rosenbrock chains (extension, BASELINE configs[0]) against the target's own moments:
+    x ~ N(1, 10), y | x ~ N(x^2, 0.1).  A random walk explores the curved ridge slowly, so the chains start
+    from exact draws of the target and the check is that the sampler keeps its moments (48 chains: loose
+    Monte-Carlo tolerances); runs are deterministic per chain id."""
+    rng = np.random.default_rng(7)
+    pts = []
+    for cid in range(48):
+        x = 1 + np.sqrt(10.0) * rng.standard_normal()
+        start = [x, x * x + np.sqrt(0.1) * rng.standard_normal()]
+        ll, s, sf, nacc = O.rosenbrock_run(100.0, 1.0, cid, start, 30000, 0, 300, 50)
+        assert np.all(np.isfinite(ll)) and nacc > 1000
+        pts.append(s)
+    a = O.rosenbrock_run(100.0, 1.0, 3, [1.0, 1.0], 2000, 0, 10, 5)
+    b = O.rosenbrock_run(100.0, 1.0, 3, [1.0, 1.0], 2000, 0, 10, 5)
+    assert np.array_equal(a[1], b[1])
+    pts = np.concatenate(pts)
+    assert abs(pts[:, 0].mean() - 1.0) < 1.2 and 5.0 < pts[:, 0].var() < 15.0
+    assert abs((pts[:, 1] - pts[:, 0] ** 2).var() - 0.1) < 0.02          # the ridge's width: y - x^2 ~ N(0, 0.1)
+    x = np.array([0.3, -0.7])
+    assert O.lib().orc_rosenbrock_eval(100.0, x.ctypes.data_as(O.C.POINTER(O.C.c_double))) == \
+        -((1 - 0.3) * (1 - 0.3) + 100.0 * ((-0.7 - 0.3 * 0.3) * (-0.7 - 0.3 * 0.3))) / 20
