@@ -107,6 +107,31 @@ int mcmc_hip_set_tables(mcmc_hip_ctx* ctx, const double* R, int32_t n_lag);
 /* data.deathsPerDay / data.deathsSigma (covid.h:47), each [n_data]. */
 int mcmc_hip_set_data(mcmc_hip_ctx* ctx, const double* deaths, const double* sigma);
 
+/* --- multi-region model (EXTENSION: BASELINE.json configs[4]; the reference models one region,
+ * covid.h:284-321).  After create + set_tables, INSTEAD of set_data: the chain's State becomes
+ * n_regions region blocks [DiseaseSpread_r (, SmoothnessPrior_r)] -- each the complete model of
+ * covid.h:325-496 with its own observations deaths/sigma [n_regions][n_data], population and
+ * hospital capacity (cap0, cap_incr_rate), everything else as in cfg -- sharing betaMild and
+ * betaHigh, which region 0 owns.  mcmc_hip_dim becomes n_regions * (nB + nDisc + 3): a parameter
+ * vector is n_regions blocks of the single-region layout, the beta slots of every block mirroring
+ * region 0's (set_chains / eval copy region 0's into them).  One MH step moves ONE region, the
+ * head, by systematic scan -- head = (random-subspace steps since set_chains) mod n_regions, the
+ * same for every chain, so wavefronts do not diverge; a given-subspace step reuses the head (as
+ * rec.whichHead does, mcmc.h:510).  The step draws what DiseaseSpread::step draws (covid.h:499-622)
+ * on the head's block, the betas' branch only for region 0; changed betas make every other region a
+ * dependent that is re-evaluated (mcmc.h:539-602); delta sums (-old + new) in State order
+ * (mcmc.h:604-606); the adjust phase corrects the head's own step size (mcmc.h:1107-1114).
+ * n_regions = 1 is the reference's State, bit for bit.  get_loglike then returns per chain (sum
+ * of the regions' model log-likelihoods, sum of their priors); the per-region values and step
+ * sizes: the two getters below.  set_state's loglike is [n][n_regions][2] here.  Not combined with
+ * the tempering ladder, the fast mode, eval_static or derive (derive a region through a
+ * single-region context). */
+int mcmc_hip_set_regions(mcmc_hip_ctx* ctx, int32_t n_regions, const int32_t* pop_size, const double* cap0,
+                         const double* cap_incr_rate, const double* deaths, const double* sigma);
+int32_t mcmc_hip_n_regions(const mcmc_hip_ctx* ctx);
+int mcmc_hip_get_region_loglike(mcmc_hip_ctx* ctx, double* out /*[n_chains][n_regions][2]*/);
+int mcmc_hip_get_region_stepsizes(mcmc_hip_ctx* ctx, double* out /*[n_chains][n_regions]*/);
+
 /* Arithmetic of the model time-stepper.  No counterpart in the reference, whose only
  * arithmetic is `using Float = double` (mcmc.h:43) = MCMC_HIP_PRECISION_F64, the default and
  * the only mode held to bit-exact parity.  MCMC_HIP_PRECISION_F32_MODEL ("fast mode", the FP32

@@ -96,6 +96,11 @@ struct mcmc_hip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int size = 0, nB = 0, dim = 0, simDays = 0, simPad = 0, nLag = 0, tabRows = 0, histRows = 0;
+    /* multi-region model (extension): dim = nRegions * dimRegion once set_regions has been called */
+    bool multi = false;
+    int nRegions = 1, dimRegion = 0;
+    long long headCounter = 0;          /* random-subspace steps since set_chains: the systematic scan's position */
+    DevBuf<double> dRegDeaths, dRegSigma2, dRegPop, dRegCap0, dRegCapRate, dLLProp;
     bool haveTables = false, haveData = false, haveChains = false;
     DevModel M{};
     ChainState S{};
@@ -279,6 +284,8 @@ template <typename K, typename... Args>
 int launch_chain_kernel(mcmc_hip_ctx* c, K kernel, bool derive, int T, Args... args) {
     const unsigned grid = (unsigned)((c->nTiles + MCMC_WAVES_PER_BLOCK - 1) / MCMC_WAVES_PER_BLOCK);
     size_t shmem = lds_bytes(c->M, derive, T);
+    if (c->multi && !derive)           /* + one region slice per wave (stage_region) */
+        shmem = ((shmem + 7) / 8 + (size_t)MCMC_WAVES_PER_BLOCK * region_slice_doubles(c->M)) * sizeof(double);
     if (shmem > kLdsMax)
         return fail(MCMC_HIP_EINVAL, "the series is too long for the LDS image (%zu B > %zu B)", shmem, kLdsMax);
     if (grid <= (unsigned)c->nCU && shmem < kLdsSolo) shmem = kLdsSolo;
@@ -289,6 +296,10 @@ int launch_chain_kernel(mcmc_hip_ctx* c, K kernel, bool derive, int T, Args... a
 }
 
 int run_eval_current(mcmc_hip_ctx* c) {
+    if (c->multi) {
+        if (c->cfg.contract) return launch_chain_kernel(c, eval_kernel<MCMC_T, true, 0, true>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
+        return launch_chain_kernel(c, eval_kernel<MCMC_T, false, 0, true>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
+    }
     if (c->precision == MCMC_HIP_PRECISION_F32_MODEL)
         return launch_chain_kernel(c, eval_kernel<MCMC_T, true, 1>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
     if (c->cfg.contract) return launch_chain_kernel(c, eval_kernel<MCMC_T, true>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
@@ -296,11 +307,17 @@ int run_eval_current(mcmc_hip_ctx* c) {
 }
 
 int launch_steps(mcmc_hip_ctx* c, int nSteps, const double* dBetas, const int* dFlags, int slot0) {
+    const long long hc = c->headCounter;
+    if (c->multi) {
+        if (c->cfg.contract)
+            return launch_chain_kernel(c, mh_step_kernel<MCMC_T, true, 0, true>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0, hc);
+        return launch_chain_kernel(c, mh_step_kernel<MCMC_T, false, 0, true>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0, hc);
+    }
     if (c->precision == MCMC_HIP_PRECISION_F32_MODEL)
-        return launch_chain_kernel(c, mh_step_kernel<MCMC_T, true, 1>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0);
+        return launch_chain_kernel(c, mh_step_kernel<MCMC_T, true, 1>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0, hc);
     if (c->cfg.contract)
-        return launch_chain_kernel(c, mh_step_kernel<MCMC_T, true>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0);
-    return launch_chain_kernel(c, mh_step_kernel<MCMC_T, false>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0);
+        return launch_chain_kernel(c, mh_step_kernel<MCMC_T, true>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0, hc);
+    return launch_chain_kernel(c, mh_step_kernel<MCMC_T, false>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0, hc);
 }
 
 int check_ctx(const mcmc_hip_ctx* c) {
@@ -331,7 +348,10 @@ int run_schedule(mcmc_hip_ctx* c, const std::vector<double>& betas, const std::v
         total += ms * 1e-3;
         c->kernelS += ms * 1e-3;
         c->kernelLaunches += 1;
-        for (int g = 0; g < cnt; ++g) if (flags[first + off + g] & SF_RECORD) ++slot;
+        for (int g = 0; g < cnt; ++g) {
+            if (flags[first + off + g] & SF_RECORD) ++slot;
+            if (flags[first + off + g] & SF_RANDOM) ++c->headCounter;
+        }
         c->stepsDone += (unsigned long long)cnt;
     }
     if (wallS) *wallS = total;
@@ -449,6 +469,7 @@ static int init_ctx(mcmc_hip_ctx* c, const mcmc_covid_config* cfg, int device) {
     c->size = cfg->max_delay + cfg->n_predict + cfg->n_data;          /* covid.h:297 */
     c->nB = cfg->n_data - cfg->fix_behavior_in_advance;               /* covid.h:299 */
     c->dim = c->nB + cfg->n_disc + 3;
+    c->dimRegion = c->dim;
     c->simDays = cfg->max_delay + cfg->n_data;                        /* what loglike can see */
     c->simPad = c->size + 2 * MCMC_T;
     c->nLag = std::min(c->size, (int)MCMC_HIP_TRAJ_NDAYS);            /* covid.h:378 */
@@ -493,6 +514,7 @@ static int init_ctx(mcmc_hip_ctx* c, const mcmc_covid_config* cfg, int device) {
     M.discThr = 2 / nNotFixed;                                        /* covid.h:581 (+inf if none fixed) */
     M.discFixedMask = mask;
     M.capacity = c->dCapacity.p; M.seg = c->dSeg.p;
+    M.nRegions = 1; M.dimRegion = c->dimRegion;
     return 0;
 }
 
@@ -561,6 +583,48 @@ int mcmc_hip_set_data(mcmc_hip_ctx* c, const double* deaths, const double* sigma
     c->M.deaths = c->dDeaths.p;
     c->M.sigma2 = c->dSigma2.p;
     c->haveData = true;
+    c->multi = false; c->nRegions = 1; c->dim = c->dimRegion;          /* back to the single-region State */
+    c->M.nRegions = 1;
+    c->haveChains = false;
+    return 0;
+} MCMC_ABI_GUARD
+
+int mcmc_hip_set_regions(mcmc_hip_ctx* c, int32_t n_regions, const int32_t* pop_size, const double* cap0,
+                         const double* cap_incr_rate, const double* deaths, const double* sigma) try {
+    if (int r = check_ctx(c)) return r;
+    if (n_regions < 1 || n_regions > 4096 || !pop_size || !cap0 || !cap_incr_rate || !deaths || !sigma)
+        return fail(MCMC_HIP_EINVAL, "set_regions: need 1..4096 regions and all five arrays");
+    if (c->precision != MCMC_HIP_PRECISION_F64) return fail(MCMC_HIP_EINVAL, "set_regions: the multi-region model runs in double only");
+    for (int r = 0; r < n_regions; ++r)
+        if (pop_size[r] < 1) return fail(MCMC_HIP_EINVAL, "set_regions: pop_size[%d] must be positive", r);
+    HIP_TRY(hipSetDevice(c->device));
+    const int R = n_regions, n = c->cfg.n_data;
+    std::vector<double> s2((size_t)R * n), pop(R);
+    for (size_t i = 0; i < s2.size(); ++i) s2[i] = sigma[i] * sigma[i];            /* covid.h:491 */
+    for (int r = 0; r < R; ++r) pop[r] = (double)pop_size[r];
+    if (int r = c->dRegDeaths.alloc((size_t)R * n)) return r;
+    if (int r = c->dRegSigma2.alloc((size_t)R * n)) return r;
+    if (int r = c->dRegPop.alloc(R)) return r;
+    if (int r = c->dRegCap0.alloc(R)) return r;
+    if (int r = c->dRegCapRate.alloc(R)) return r;
+    HIP_TRY(hipMemcpy(c->dRegDeaths.p, deaths, (size_t)R * n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->dRegSigma2.p, s2.data(), s2.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->dRegPop.p, pop.data(), R * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->dRegCap0.p, cap0, R * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->dRegCapRate.p, cap_incr_rate, R * sizeof(double), hipMemcpyHostToDevice));
+    /* the shared LDS image still wants a series (its slots are overridden per region): region 0's */
+    if (int r = c->dDeaths.alloc(n)) return r;
+    if (int r = c->dSigma2.alloc(n)) return r;
+    HIP_TRY(hipMemcpy(c->dDeaths.p, deaths, n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->dSigma2.p, s2.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    DevModel& M = c->M;
+    M.deaths = c->dDeaths.p; M.sigma2 = c->dSigma2.p;
+    M.nRegions = R; M.dimRegion = c->dimRegion;
+    M.regDeaths = c->dRegDeaths.p; M.regSigma2 = c->dRegSigma2.p; M.regPop = c->dRegPop.p;
+    M.regCap0 = c->dRegCap0.p; M.regCapRate = c->dRegCapRate.p;
+    c->multi = true; c->nRegions = R; c->dim = R * c->dimRegion;
+    c->haveData = true;
+    c->haveChains = false;
     return 0;
 } MCMC_ABI_GUARD
 
@@ -571,6 +635,7 @@ int mcmc_hip_set_precision(mcmc_hip_ctx* c, int32_t mode) try {
     if (mode == MCMC_HIP_PRECISION_F32_MODEL) {
         if (!c->haveTables) return fail(MCMC_HIP_ESTATE, "set_precision: call set_tables first");
         if (!c->cfg.contract) return fail(MCMC_HIP_EINVAL, "set_precision: the fast mode needs cfg.contract = 1");
+        if (c->multi) return fail(MCMC_HIP_EINVAL, "set_precision: the multi-region model runs in double only");
     }
     c->precision = mode;
     c->haveChains = false;             /* log-likelihoods of the other arithmetic are not comparable */
@@ -602,8 +667,10 @@ int mcmc_hip_set_chains(mcmc_hip_ctx* c, int64_t n_chains, const double* params,
     c->haveChains = false;
     c->nChains = n; c->nP = nP; c->nTiles = (int)(nP / MCMC_WAVE);
     if (int r = c->dParams.alloc((size_t)2 * dim * nP)) return r;
-    if (int r = c->dLL.alloc(2 * nP)) return r;
-    if (int r = c->dStepsize.alloc(nP)) return r;
+    const int R = c->nRegions;
+    if (int r = c->dLL.alloc((size_t)2 * R * nP)) return r;
+    if (int r = c->dStepsize.alloc((size_t)R * nP)) return r;
+    if (c->multi) { if (int r = c->dLLProp.alloc((size_t)R * nP)) return r; }
     if (int r = c->dRng.alloc(2 * nP)) return r;
     if (int r = c->dNAccept.alloc(nP)) return r;
     if (int r = c->dPairs.alloc(2 * nP)) return r;
@@ -615,6 +682,8 @@ int mcmc_hip_set_chains(mcmc_hip_ctx* c, int64_t n_chains, const double* params,
     S.rng = c->dRng.p; S.nAccept = c->dNAccept.p; S.pairs = c->dPairs.p; S.mean = c->dMean.p;
     S.recLL = nullptr; S.recSamples = nullptr; S.nChains = n; S.dim = dim;
     S.chainBeta = nullptr; c->ladderK = 0; c->nLadders = 0;         /* a new set of chains has no ladder */
+    S.llProp = c->multi ? c->dLLProp.p : nullptr;
+    c->headCounter = 0;
     if (int r = alloc_work(c, nP)) return r;
 
     /* upload chain-major params and transpose to SoA on the device */
@@ -624,22 +693,27 @@ int mcmc_hip_set_chains(mcmc_hip_ctx* c, int64_t n_chains, const double* params,
     const unsigned tb = 256, tg = (unsigned)((nP + tb - 1) / tb);
     hipLaunchKernelGGL(tile_in_kernel<double>, dim3(tg), dim3(tb), 0, c->stream, (const double*)stage.p, S.params, n, dim, nP);
     HIP_TRY(hipGetLastError());
+    if (c->multi && R > 1) {           /* the shared betas are region 0's: mirror them into every block */
+        hipLaunchKernelGGL(mirror_betas_kernel, dim3(tg), dim3(tb), 0, c->stream, S.params, nP, R, c->dimRegion, c->nB + c->cfg.n_disc);
+        HIP_TRY(hipGetLastError());
+    }
     /* MetropolisChain::mean starts as a deep copy of the state (mcmc.h:1002) */
     HIP_TRY(hipMemcpyAsync(c->dMean.p, S.params, (size_t)dim * nP * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(S.params + (size_t)dim * nP, 0, (size_t)dim * nP * sizeof(double), c->stream));
     HIP_TRY(hipMemsetAsync(S.nAccept, 0, nP * sizeof(int), c->stream));
     HIP_TRY(hipMemsetAsync(S.pairs, 0, 2 * nP * sizeof(unsigned long long), c->stream));
 
-    std::vector<double> ss(nP, 1.0);
+    std::vector<double> ss((size_t)R * nP, 1.0);                    /* [tile][R][64]: every region starts at the chain's */
     std::vector<uint64_t> rng(2 * nP);
     for (long long i = 0; i < nP; ++i) {
         const long long src = i < n ? i : n - 1;
-        if (stepsizes) ss[i] = stepsizes[src];
+        if (stepsizes)
+            for (int q = 0; q < R; ++q) ss[((size_t)(i / MCMC_WAVE) * R + q) * MCMC_WAVE + (size_t)(i % MCMC_WAVE)] = stepsizes[src];
         const uint64_t id = chain_ids ? chain_ids[src] : first_chain_id + (uint64_t)src;
         const size_t t0 = (size_t)(i / MCMC_WAVE) * 2 * MCMC_WAVE + (size_t)(i % MCMC_WAVE);
         pcg32_seed(rng[t0], rng[t0 + MCMC_WAVE], 0, id);             /* rnd(0, chainid), mcmc.h:999 */
     }
-    HIP_TRY(hipMemcpyAsync(S.stepsize, ss.data(), nP * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(S.stepsize, ss.data(), ss.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(S.rng, rng.data(), 2 * nP * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     if (int r = run_eval_current(c)) return r;                       /* State::eval, mcmc.h:385-393 */
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -658,7 +732,7 @@ int mcmc_hip_set_state(mcmc_hip_ctx* c, const uint64_t* rng_state, const double*
             if (!(rng_state[2 * i + 1] & 1u)) return fail(MCMC_HIP_EINVAL, "set_state: chain %lld: a pcg32 increment is odd by construction", i);
         if (int r = upload_field<uint64_t>(c, rng_state, 2, c->S.rng)) return r;
     }
-    if (loglike) { if (int r = upload_field<double>(c, loglike, 2, c->S.ll)) return r; }
+    if (loglike) { if (int r = upload_field<double>(c, loglike, 2 * c->nRegions, c->S.ll)) return r; }
     if (mean) { if (int r = upload_field<double>(c, mean, c->dim, c->dMean.p)) return r; }
     if (accept_counts) { if (int r = upload_field<int>(c, accept_counts, 1, c->S.nAccept)) return r; }
     return 0;
@@ -679,6 +753,7 @@ int mcmc_hip_set_ladder(mcmc_hip_ctx* c, int32_t n_temps, const double* temps, u
     if (int r = check_ctx(c)) return r;
     if (!c->haveChains) return fail(MCMC_HIP_ESTATE, "set_ladder: call set_chains first");
     if (n_temps == 0) { c->S.chainBeta = nullptr; c->ladderK = 0; c->nLadders = 0; return 0; }
+    if (c->multi) return fail(MCMC_HIP_EINVAL, "set_ladder: the tempering ladder takes the single-region State");
     if (n_temps < 2 || !temps) return fail(MCMC_HIP_EINVAL, "set_ladder: need n_temps >= 2 and temps");
     if (c->nChains % n_temps != 0) return fail(MCMC_HIP_EINVAL, "set_ladder: n_chains must be a multiple of n_temps");
     for (int r = 0; r < n_temps; ++r)
@@ -883,12 +958,33 @@ int mcmc_hip_get_params(mcmc_hip_ctx* c, double* out) try {
 } MCMC_ABI_GUARD
 int mcmc_hip_get_loglike(mcmc_hip_ctx* c, double* out) try {
     if (int r = need_chains(c, out)) return r;
-    return copy_field<double>(c, c->S.ll, 2, out);
+    if (c->nRegions == 1) return copy_field<double>(c, c->S.ll, 2, out);
+    std::vector<double> all((size_t)c->nChains * 2 * c->nRegions);     /* summed in State order */
+    if (int r = copy_field<double>(c, c->S.ll, 2 * c->nRegions, all.data())) return r;
+    for (long long i = 0; i < c->nChains; ++i) {
+        double m = 0, p = 0;
+        for (int q = 0; q < c->nRegions; ++q) { m += all[((size_t)i * c->nRegions + q) * 2]; p += all[((size_t)i * c->nRegions + q) * 2 + 1]; }
+        out[2 * i] = m; out[2 * i + 1] = p;
+    }
+    return 0;
+} MCMC_ABI_GUARD
+int mcmc_hip_get_region_loglike(mcmc_hip_ctx* c, double* out) try {
+    if (int r = need_chains(c, out)) return r;
+    return copy_field<double>(c, c->S.ll, 2 * c->nRegions, out);
 } MCMC_ABI_GUARD
 int mcmc_hip_get_stepsizes(mcmc_hip_ctx* c, double* out) try {
     if (int r = need_chains(c, out)) return r;
-    return copy_field<double>(c, c->S.stepsize, 1, out);
+    if (c->nRegions == 1) return copy_field<double>(c, c->S.stepsize, 1, out);
+    std::vector<double> all((size_t)c->nChains * c->nRegions);
+    if (int r = copy_field<double>(c, c->S.stepsize, c->nRegions, all.data())) return r;
+    for (long long i = 0; i < c->nChains; ++i) out[i] = all[(size_t)i * c->nRegions];      /* region 0's */
+    return 0;
 } MCMC_ABI_GUARD
+int mcmc_hip_get_region_stepsizes(mcmc_hip_ctx* c, double* out) try {
+    if (int r = need_chains(c, out)) return r;
+    return copy_field<double>(c, c->S.stepsize, c->nRegions, out);
+} MCMC_ABI_GUARD
+int32_t mcmc_hip_n_regions(const mcmc_hip_ctx* c) { return c ? c->nRegions : MCMC_HIP_EINVAL; }
 int mcmc_hip_get_accept_counts(mcmc_hip_ctx* c, int32_t* out) try {
     if (int r = need_chains(c, out)) return r;
     return copy_field<int>(c, c->S.nAccept, 1, out);
@@ -935,11 +1031,15 @@ static int with_external(mcmc_hip_ctx* c, int64_t n, const double* params, bool 
     if (int r = check_ctx(c)) return r;
     if (!c->haveTables || !c->haveData) return fail(MCMC_HIP_ESTATE, "call set_tables and set_data first");
     if (n < 1 || !params || !out) return fail(MCMC_HIP_EINVAL, "need n >= 1, params and an output buffer");
+    if (derive && c->nRegions > 1)
+        return fail(MCMC_HIP_EINVAL, "derive: one region at a time (a single-region context with that region's data)");
     HIP_TRY(hipSetDevice(c->device));
     const long long nP = (n + MCMC_WAVE - 1) / MCMC_WAVE * MCMC_WAVE;
     const int dim = c->dim;
+    const int R = c->nRegions;
     /* a temporary lane set so that chain state is untouched */
     mcmc_hip_ctx tmp;
+    tmp.multi = c->multi && !derive; tmp.nRegions = R; tmp.dimRegion = c->dimRegion;
     tmp.cfg = c->cfg; tmp.device = c->device; tmp.nCU = c->nCU; tmp.stream = c->stream; tmp.size = c->size;
     tmp.simPad = c->simPad; tmp.histRows = c->histRows; tmp.dim = dim; tmp.nP = nP; tmp.nChains = n;
     tmp.M = c->M; tmp.nTiles = (int)(nP / MCMC_WAVE);
@@ -949,29 +1049,42 @@ static int with_external(mcmc_hip_ctx* c, int64_t n, const double* params, bool 
         if ((rc = alloc_work(&tmp, nP))) break;
         if ((rc = stage.alloc((size_t)n * dim))) break;
         if ((rc = soa.alloc((size_t)dim * nP))) break;
-        if ((rc = res.alloc(derive ? (size_t)9 * c->size * nP : (size_t)2 * nP))) break;
+        if ((rc = res.alloc(derive ? (size_t)9 * c->size * nP : (size_t)2 * R * nP))) break;
         tmp.S.dim = dim; tmp.S.nChains = n;
         hipError_t e = hipMemcpyAsync(stage.p, params, (size_t)n * dim * sizeof(double), hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) { rc = fail(MCMC_HIP_EHIP, "upload failed: %s", hipGetErrorString(e)); break; }
         const unsigned tb = 256, tg = (unsigned)((nP + tb - 1) / tb);
         hipLaunchKernelGGL(tile_in_kernel<double>, dim3(tg), dim3(tb), 0, c->stream, (const double*)stage.p, soa.p, (long long)n, dim, nP);
+        if (tmp.multi && R > 1)
+            hipLaunchKernelGGL(mirror_betas_kernel, dim3(tg), dim3(tb), 0, c->stream, soa.p, nP, R, c->dimRegion, c->nB + c->cfg.n_disc);
         if (derive) {
             if (c->cfg.contract) rc = launch_chain_kernel(&tmp, derive_kernel<MCMC_T_DERIVE, true>, true, MCMC_T_DERIVE, tmp.M, tmp.S, (const double*)soa.p, res.p);
             else rc = launch_chain_kernel(&tmp, derive_kernel<MCMC_T_DERIVE, false>, true, MCMC_T_DERIVE, tmp.M, tmp.S, (const double*)soa.p, res.p);
+        } else if (tmp.multi) {
+            if (c->cfg.contract) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true, 0, true>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
+            else rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, false, 0, true>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
         } else {
             if (c->precision == MCMC_HIP_PRECISION_F32_MODEL) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true, 1>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
             else if (c->cfg.contract) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
             else rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, false>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
         }
         if (rc) break;
-        const int rows = derive ? 9 * c->size : 2;
+        const int rows = derive ? 9 * c->size : 2 * R;
         std::vector<double> h((size_t)rows * nP);
         e = hipMemcpyAsync(h.data(), res.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { rc = fail(MCMC_HIP_EHIP, "kernel or download failed: %s", hipGetErrorString(e)); break; }
-        for (long long i = 0; i < n; ++i)
-            for (int r = 0; r < rows; ++r)
-                out[i * rows + r] = h[((size_t)(i / MCMC_WAVE) * rows + r) * MCMC_WAVE + (size_t)(i % MCMC_WAVE)];
+        auto at = [&](long long i, int r) { return h[((size_t)(i / MCMC_WAVE) * rows + r) * MCMC_WAVE + (size_t)(i % MCMC_WAVE)]; };
+        if (!derive && R > 1) {                      /* (sum of the regions' models, sum of their priors), State order */
+            for (long long i = 0; i < n; ++i) {
+                double m = 0, p = 0;
+                for (int q = 0; q < R; ++q) { m += at(i, 2 * q); p += at(i, 2 * q + 1); }
+                out[2 * i] = m; out[2 * i + 1] = p;
+            }
+        } else {
+            for (long long i = 0; i < n; ++i)
+                for (int r = 0; r < rows; ++r) out[i * rows + r] = at(i, r);
+        }
     } while (0);
     tmp.stream = nullptr;      /* borrowed */
     return rc;
@@ -1004,6 +1117,7 @@ int mcmc_hip_eval_static(mcmc_hip_ctx* c, int64_t n, const double* params_dev, d
         return fail(MCMC_HIP_EINVAL, "eval_static: %lld parameter vectors exceed the static scratch (%u bytes hold at most %lld "
                     "vectors of this model); use mcmc_hip_eval", (long long)n, (unsigned)MCMC_STATIC_SCRATCH_BYTES, (long long)nMax);
     if (!c->staticScratch) return fail(MCMC_HIP_ESTATE, "eval_static: no static scratch address for this device");
+    if (c->multi) return fail(MCMC_HIP_EINVAL, "eval_static: single-region contexts only");
     HIP_TRY(hipSetDevice(c->device));
     const long long nP = (n + MCMC_WAVE - 1) / MCMC_WAVE * MCMC_WAVE;
     const int dim = c->dim;

@@ -81,6 +81,13 @@ struct DevModel {
     const int* seg;               /* [simPad] piecewise-constant segment of day i, -1 = none */
     const float* RF;              /* fast mode only (mcmc_model_f32.hip.h): [rowsF][8] floats, or null */
     const float* RFn;             /* fast mode only: [rowsF][4] floats                                  */
+    /* multi-region model (extension, see "Multi-region" below): R region blocks per chain */
+    int nRegions, dimRegion;      /* 1 and nB+nDisc+3 for the reference's single-region State            */
+    const double* regDeaths;      /* [R][nData]                                                          */
+    const double* regSigma2;      /* [R][nData]                                                          */
+    const double* regPop;         /* [R] population, cap0, cap_incr_rate of every region                 */
+    const double* regCap0;
+    const double* regCapRate;
 };
 
 /* ------------------------------------------------------------------- pcg32 ---- */
@@ -975,7 +982,7 @@ __device__ inline void load_lane_scalars(const DevModel& M, const double* x_u, u
  */
 __device__ inline bool propose(const DevModel& M, Pcg32& rnd, const double* __restrict__ xc_u,
                                double* __restrict__ xp_u, unsigned lane, double stepsize, LaneScalars& lp,
-                               double& priorOut) {
+                               double& priorOut, bool withBetas = true) {
     load_lane_scalars(M, xc_u, lane, lp);
     double disc[MCMC_MAXDISC];
 #pragma unroll
@@ -994,7 +1001,9 @@ __device__ inline bool propose(const DevModel& M, Pcg32& rnd, const double* __re
         if (big1) lp.delay += (rnd.next_double() - 0.5) * sfmin;
         lp.delay = bound_reflect(lp.delay, 5.0, (double)M.md);
     }
-    if (rnd.next_float() < 0.3f) {                                  /* covid.h:518-532 */
+    /* withBetas is false only for a region of the multi-region model that does not own the shared
+     * betas: it skips their branch, gate draw included */
+    if (withBetas && rnd.next_float() < 0.3f) {                     /* covid.h:518-532 */
         if (!big2) lp.betaMild += (rnd.next_double() - 0.5) * 0.1 * sfmin;
         else lp.betaMild += (rnd.next_double() - 0.5) * sfmin;
         lp.betaMild = bound_reflect(lp.betaMild, 0.0, 100.0);
@@ -1095,8 +1104,8 @@ __device__ inline bool propose(const DevModel& M, Pcg32& rnd, const double* __re
 struct ChainState {
     double* params;               /* [nTiles][dim][64] current state of every chain      */
     double* prop;                 /* [nTiles][dim][64] proposal scratch                  */
-    double* ll;                   /* [nTiles][2][64]: model, prior                       */
-    double* stepsize;             /* [nTiles][64]                                        */
+    double* ll;                   /* [nTiles][2R][64]: (model, prior) of every region    */
+    double* stepsize;             /* [nTiles][R][64]                                     */
     uint64_t* rng;                /* [nTiles][2][64]: state, inc                         */
     int* nAccept;                 /* [nTiles][64]                                        */
     unsigned long long* pairs;    /* [nTiles][2][64]: WorkCount algo, exec               */
@@ -1106,6 +1115,7 @@ struct ChainState {
     double* recLL;                /* [nSavedCap][nTiles][64]                             */
     double* recSamples;           /* [nSavedCap][nTiles][dim][64] or null                */
     const double* chainBeta;      /* [nTiles][64] inverse temperature of the chain's rung, or null */
+    double* llProp;               /* [nTiles][R][64] multi-region only: proposed model log-likelihoods */
     long long nChains;
     int nTiles;
     int dim;
@@ -1136,16 +1146,57 @@ __device__ __forceinline__ WaveBases wave_bases(const DevModel& M, const ChainSt
     return B;
 }
 
+/* ------------------------------------------------------------ multi-region ---- */
+/* EXTENSION (BASELINE.json configs[4]; the reference has one region, covid.h:284-321): a chain's
+ * State is R region blocks [DiseaseSpread_r (, SmoothnessPrior_r)] -- each the complete covid.h
+ * model with observations, population and hospital capacity of its own -- sharing betaMild and
+ * betaHigh, which region 0 owns.  Parameter vector: R blocks of the single-region layout; the beta
+ * slots of every block mirror region 0's.  One MH step moves ONE region, the head, by SYSTEMATIC
+ * scan: head = (number of random-subspace steps so far) mod R, a given-subspace step reuses it.
+ * The head is the same for every chain, so a wavefront never diverges on it (a per-chain random
+ * head would make every wave evaluate ~min(R, 64) regions per step for 64 useful evaluations).
+ * Region 0's step includes the betas' branch; if a lane's betas changed, all other regions are its
+ * dependents and are re-evaluated with them (mcmc.h:539-602); delta sums (-old + new) over the
+ * evaluated likelihoods in State order DS_0, P_0, DS_1, P_1, ... (mcmc.h:604-606).  With R = 1
+ * every operation is the single-region kernel's.  Oracle: orc_multi_step / orc_multi_run.
+ *
+ * Region data is wave-uniform but differs between the regions a wave walks through, so each wave
+ * stages the current region's observations and capacity curve into an LDS slice of its own
+ * (behind the workgroup's shared image; no barrier: only this wave reads it). */
+__host__ __device__ inline size_t region_slice_doubles(const DevModel& M) {
+    return (size_t)M.simPad + 2 * (size_t)M.nData;
+}
+__device__ __forceinline__ LdsView stage_region(const DevModel& M, const LdsView& shared, double* slice, int q,
+                                                unsigned lane, double& popOut) {
+    double* cap = slice;
+    double* dea = cap + M.simPad;
+    double* sg2 = dea + M.nData;
+    const double cap0 = M.regCap0[q], rate = M.regCapRate[q];
+    for (int i = lane; i < M.simPad; i += MCMC_WAVE) cap[i] = cap0 + fmax(rate * (double)(i - M.md), 0.0);   /* covid.h:314 */
+    for (int i = lane; i < M.nData; i += MCMC_WAVE) {
+        dea[i] = M.regDeaths[(size_t)q * M.nData + i];
+        sg2[i] = M.regSigma2[(size_t)q * M.nData + i];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);        /* lgkmcnt(0): the slice is written before any lane reads it */
+    __builtin_amdgcn_wave_barrier();
+    popOut = M.regPop[q];
+    LdsView v = shared;
+    v.capacity = cap; v.deaths = dea; v.sigma2 = sg2;
+    return v;
+}
+
 /*
  * n_steps Metropolis-Hastings steps for every chain: Target::step (mcmc.h:750-783) with
  * State::step_random/given_subspace (mcmc.h:494-610), DiseaseSpread::step (covid.h:499-627),
  * SmoothnessPrior::eval (mcmc.h:197-214), State::accept (mcmc.h:653-661) and the per-step
  * bookkeeping of MetropolisChain::run (mcmc.h:1023-1127) driven by `flags`.
+ * MULTI: the multi-region State (see above); headCounter = random-subspace steps before this launch.
  */
-template <int T, bool FUSE, int PREC = 0>
+template <int T, bool FUSE, int PREC = 0, bool MULTI = false>
 __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n_steps,
                                                  const double* __restrict__ betas,
-                                                 const int* __restrict__ flags, int slot0) {
+                                                 const int* __restrict__ flags, int slot0, long long headCounter) {
+    static_assert(!(MULTI && PREC != 0), "the multi-region model runs in double only");
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     const LdsView lds = stage_lds(M, lds_raw, false, T);
     const unsigned lane = threadIdx.x & (MCMC_WAVE - 1);
@@ -1156,14 +1207,21 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
     double* xcw_u = S.params + (size_t)tile * tileVec;
     double* xp_u = S.prop + (size_t)tile * tileVec;
     uint64_t* rng_u = S.rng + (size_t)tile * 2 * MCMC_WAVE;
-    double* ll_u = S.ll + (size_t)tile * 2 * MCMC_WAVE;
+    const int R = MULTI ? M.nRegions : 1;
+    const int dimR = MULTI ? M.dimRegion : S.dim;
+    double* ll_u = S.ll + (size_t)tile * 2 * R * MCMC_WAVE;
+    double* ss_u = S.stepsize + (size_t)tile * R * MCMC_WAVE;
     const size_t flat = (size_t)tile * MCMC_WAVE + lane;
 
     Pcg32 rnd;
     rnd.state = rng_u[lane];
     rnd.inc = rng_u[MCMC_WAVE + lane];
-    double llModel = ll_u[lane], llPrior = ll_u[MCMC_WAVE + lane];
-    double stepsize = S.stepsize[flat];
+    double llModel = 0, llPrior = 0, stepsize = 1;
+    if constexpr (!MULTI) {
+        llModel = ll_u[lane];
+        llPrior = ll_u[MCMC_WAVE + lane];
+        stepsize = ss_u[lane];
+    }
     int nAccept = S.nAccept[flat];
     unsigned long long* pairs_u = S.pairs + (size_t)tile * 2 * MCMC_WAVE;
     WorkCount work;
@@ -1175,6 +1233,17 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
     pc.start();
     /* tempering ladder (extension): the chain's rung multiplies the target's beta */
     const double rungBeta = S.chainBeta ? S.chainBeta[flat] : 1.0;
+    /* multi-region: this wave's LDS slice, the head of the scan */
+    double* slice = nullptr;
+    double* llp_u = nullptr;
+    long long scan = headCounter;
+    int head = 0;
+    if constexpr (MULTI) {
+        const int waveInBlock = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / MCMC_WAVE));
+        slice = lds_raw + (lds_bytes(M, false, T) + 7) / 8 + (size_t)waveInBlock * region_slice_doubles(M);
+        llp_u = S.llProp + (size_t)tile * R * MCMC_WAVE;
+        head = scan > 0 ? (int)((scan - 1) % R) : 0;
+    }
 
 #pragma unroll 1
     for (int g = 0; g < n_steps; ++g) {
@@ -1184,8 +1253,15 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
         if (fl & SF_RESET_ACC) nAccept = 0;                         /* mcmc.h:1032,1090 */
         if (fl & SF_RECORD) {                                       /* mcmc.h:1037-1062 */
             double l = 0;
-            l += llModel;
-            if (M.hasPrior) l += llPrior;
+            if constexpr (MULTI) {
+                for (int q = 0; q < R; ++q) {                       /* State::loglikelihood, mcmc.h:612-618 */
+                    l += ll_u[(2 * q) * MCMC_WAVE + lane];
+                    if (M.hasPrior) l += ll_u[(2 * q + 1) * MCMC_WAVE + lane];
+                }
+            } else {
+                l += llModel;
+                if (M.hasPrior) l += llPrior;
+            }
             S.recLL[((size_t)slot * S.nTiles + tile) * MCMC_WAVE + lane] = 0.0 + beta * l; /* log(weight()==1) = 0 */
             if (S.recSamples) {
                 double* dst = S.recSamples + ((size_t)slot * S.nTiles + tile) * tileVec;
@@ -1200,88 +1276,193 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
 
         if (fl & SF_RANDOM) {                                       /* mcmc.h:494-500 */
             const int nState = M.hasPrior ? 2 : 1;
-            int head;
+            int hd;
             do {
                 const float f = rnd.next_float() * (float)nState;
-                head = min((int)f, nState - 1);
-            } while (head != 0);    /* SmoothnessPrior has no steppable coords: redraw */
+                hd = min((int)f, nState - 1);
+            } while (hd != 0);    /* SmoothnessPrior has no steppable coords: redraw */
+            if constexpr (MULTI) { head = (int)(scan % R); ++scan; }
         }
 
         pc.stamp(PH_RECORD);
         LaneScalars lp;
         double llpNew;
-        const bool behChanged = propose(M, rnd, xc_u, xp_u, lane, stepsize, lp, llpNew);
-        pc.stamp(PH_PROPOSE);
-        double llm;
-        if constexpr (PREC == 1) llm = eval_model_f32<MCMC_TF>(M, lds, B, lp, lane, work, pc);   /* fast mode */
-        else llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, work, pc);
-        double llp = 0.0;
-        double delta = 0;                                           /* mcmc.h:604-606 */
-        delta += -llModel + llm;
-        if (M.hasPrior) {
-            llp = behChanged ? llpNew : llPrior;     /* unchanged behaviour: the prior keeps its value */
-            delta += -llPrior + llp;
-        }
-        pc.stamp(PH_PRIOR);
-        delta += 0.0;                                               /* log(wNew)-log(wOld), mcmc.h:765 */
-        delta *= beta;                                              /* mcmc.h:766 */
-        const double u = (double)rnd.next_float();
-        const bool accept = u < 1.0 * mcmc_exp(delta);              /* mcmc.h:776 */
-        if (__any(accept)) {                                        /* State::accept, mcmc.h:653-661 */
-            constexpr int AB = MCMC_ACC_BATCH;
-#pragma unroll 1
-            for (int k0 = 0; k0 < S.dim; k0 += AB) {
-                double vv[AB];
-#pragma unroll
-                for (int j = 0; j < AB; ++j) vv[j] = xp_u[min(k0 + j, S.dim - 1) * MCMC_WAVE + lane];
-#pragma unroll
-                for (int j = 0; j < AB; ++j)
-                    if (accept && k0 + j < S.dim) xcw_u[(k0 + j) * MCMC_WAVE + lane] = vv[j];
+        bool accept;
+        if constexpr (!MULTI) {
+            const bool behChanged = propose(M, rnd, xc_u, xp_u, lane, stepsize, lp, llpNew);
+            pc.stamp(PH_PROPOSE);
+            double llm;
+            if constexpr (PREC == 1) llm = eval_model_f32<MCMC_TF>(M, lds, B, lp, lane, work, pc);   /* fast mode */
+            else llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, work, pc);
+            double llp = 0.0;
+            double delta = 0;                                           /* mcmc.h:604-606 */
+            delta += -llModel + llm;
+            if (M.hasPrior) {
+                llp = behChanged ? llpNew : llPrior;     /* unchanged behaviour: the prior keeps its value */
+                delta += -llPrior + llp;
             }
-        }
-        if (accept) {
-            llModel = llm;
-            llPrior = llp;
-            ++nAccept;
-        }
-        if (fl & SF_ADJUST_END) {                                   /* mcmc.h:1107-1114 */
-            const double acceptRate = (double)nAccept / 20;
-            stepsize *= rate2corr(acceptRate);
+            pc.stamp(PH_PRIOR);
+            delta += 0.0;                                               /* log(wNew)-log(wOld), mcmc.h:765 */
+            delta *= beta;                                              /* mcmc.h:766 */
+            const double u = (double)rnd.next_float();
+            accept = u < 1.0 * mcmc_exp(delta);                         /* mcmc.h:776 */
+            if (__any(accept)) {                                        /* State::accept, mcmc.h:653-661 */
+                constexpr int AB = MCMC_ACC_BATCH;
+#pragma unroll 1
+                for (int k0 = 0; k0 < S.dim; k0 += AB) {
+                    double vv[AB];
+#pragma unroll
+                    for (int j = 0; j < AB; ++j) vv[j] = xp_u[min(k0 + j, S.dim - 1) * MCMC_WAVE + lane];
+#pragma unroll
+                    for (int j = 0; j < AB; ++j)
+                        if (accept && k0 + j < S.dim) xcw_u[(k0 + j) * MCMC_WAVE + lane] = vv[j];
+                }
+            }
+            if (accept) {
+                llModel = llm;
+                llPrior = llp;
+                ++nAccept;
+            }
+            if (fl & SF_ADJUST_END) {                                   /* mcmc.h:1107-1114 */
+                const double acceptRate = (double)nAccept / 20;
+                stepsize *= rate2corr(acceptRate);
+            }
+        } else {
+            const double* xcH_u = xc_u + (size_t)head * dimR * MCMC_WAVE;
+            double* xpH_u = xp_u + (size_t)head * dimR * MCMC_WAVE;
+            const int iBeta = M.nB + M.nDisc;
+            const double bmOld = xcH_u[iBeta * MCMC_WAVE + lane], bhOld = xcH_u[(iBeta + 1) * MCMC_WAVE + lane];
+            stepsize = ss_u[head * MCMC_WAVE + lane];
+            const bool behChanged = propose(M, rnd, xcH_u, xpH_u, lane, stepsize, lp, llpNew, head == 0);
+            pc.stamp(PH_PROPOSE);
+            const bool needAll = (lp.betaMild != bmOld) || (lp.betaHigh != bhOld);
+            const bool waveAll = __builtin_amdgcn_readfirstlane(__any(needAll) ? 1 : 0) != 0;
+            double llp = 0.0;
+            double delta = 0;                                           /* mcmc.h:604-606, State order */
+#pragma unroll 1
+            for (int q = 0; q < R; ++q) {
+                if (q != head && !waveAll) continue;
+                DevModel Mq = M;
+                const LdsView ldsq = stage_region(M, lds, slice, q, lane, Mq.pop);
+                WaveBases Bq = B;
+                LaneScalars lpq = lp;
+                if (q == head) {
+                    Bq.x_u = xpH_u;
+                } else {                                 /* a dependent: its own coordinates, the head's new betas */
+                    Bq.x_u = xc_u + (size_t)q * dimR * MCMC_WAVE;
+                    lpq.delay = Bq.x_u[(iBeta + 2) * MCMC_WAVE + lane];
+                }
+                const double llm = eval_model<T, FUSE, false>(Mq, ldsq, Bq, lpq, lane, work, pc);
+                llp_u[q * MCMC_WAVE + lane] = llm;
+                if (q == head || needAll) delta += -ll_u[(2 * q) * MCMC_WAVE + lane] + llm;
+                if (q == head && M.hasPrior) {
+                    const double llpOld = ll_u[(2 * q + 1) * MCMC_WAVE + lane];
+                    llp = behChanged ? llpNew : llpOld;
+                    delta += -llpOld + llp;
+                }
+            }
+            pc.stamp(PH_PRIOR);
+            delta += 0.0;
+            delta *= beta;
+            const double u = (double)rnd.next_float();
+            accept = u < 1.0 * mcmc_exp(delta);
+            if (__any(accept)) {
+                double* xcH_w = xcw_u + (size_t)head * dimR * MCMC_WAVE;
+                constexpr int AB = 16;
+#pragma unroll 1
+                for (int k0 = 0; k0 < dimR; k0 += AB) {
+                    double vv[AB];
+#pragma unroll
+                    for (int j = 0; j < AB; ++j) vv[j] = xpH_u[min(k0 + j, dimR - 1) * MCMC_WAVE + lane];
+#pragma unroll
+                    for (int j = 0; j < AB; ++j)
+                        if (accept && k0 + j < dimR) xcH_w[(k0 + j) * MCMC_WAVE + lane] = vv[j];
+                }
+                for (int q = 0; q < R; ++q) {
+                    if (q != head && !waveAll) continue;
+                    const double llm = llp_u[q * MCMC_WAVE + lane];
+                    if (accept && (q == head || needAll)) {
+                        ll_u[(2 * q) * MCMC_WAVE + lane] = llm;
+                        xcw_u[((size_t)q * dimR + iBeta) * MCMC_WAVE + lane] = lp.betaMild;      /* the shared betas */
+                        xcw_u[((size_t)q * dimR + iBeta + 1) * MCMC_WAVE + lane] = lp.betaHigh;
+                    }
+                }
+                if (accept && M.hasPrior) ll_u[(2 * head + 1) * MCMC_WAVE + lane] = llp;
+            }
+            if (accept) ++nAccept;
+            if (fl & SF_ADJUST_END) {                                   /* the head's own step size, mcmc.h:1107-1114 */
+                const double acceptRate = (double)nAccept / 20;
+                stepsize *= rate2corr(acceptRate);
+            }
+            ss_u[head * MCMC_WAVE + lane] = stepsize;
         }
         pc.stamp(PH_ACCEPT);
     }
     pc.flush(lane);
 
     rng_u[lane] = rnd.state;
-    ll_u[lane] = llModel;
-    ll_u[MCMC_WAVE + lane] = llPrior;
-    S.stepsize[flat] = stepsize;
+    if constexpr (!MULTI) {
+        ll_u[lane] = llModel;
+        ll_u[MCMC_WAVE + lane] = llPrior;
+        ss_u[lane] = stepsize;
+    }
     S.nAccept[flat] = nAccept;
     pairs_u[lane] = work.algo;
     pairs_u[MCMC_WAVE + lane] = work.exec;
 }
 
 /* State::eval (mcmc.h:385-393) of parameter vectors laid out [nTiles][dim][64]:
- * llOut[nTiles][2][64] */
-template <int T, bool FUSE, int PREC = 0>
+ * llOut[nTiles][2R][64] (R = 1 unless MULTI: every region's model and prior log-likelihood) */
+template <int T, bool FUSE, int PREC = 0, bool MULTI = false>
 __global__ MCMC_KERNEL_ATTRS void eval_kernel(DevModel M, ChainState S, const double* x, double* llOut) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     const LdsView lds = stage_lds(M, lds_raw, false, T);
     const unsigned lane = threadIdx.x & (MCMC_WAVE - 1);
     const int tile = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * MCMC_WAVES_PER_BLOCK + threadIdx.x / MCMC_WAVE));
     if (tile >= S.nTiles) return;
-    const WaveBases B = wave_bases(M, S, tile, x + (size_t)tile * S.dim * MCMC_WAVE);
-    LaneScalars lp;
-    load_lane_scalars(M, B.x_u, lane, lp);
+    WaveBases B = wave_bases(M, S, tile, x + (size_t)tile * S.dim * MCMC_WAVE);
     WorkCount work = {0, 0};
     PhaseClock pc;
     pc.start();
-    double llm;
-    if constexpr (PREC == 1) llm = eval_model_f32<MCMC_TF>(M, lds, B, lp, lane, work, pc);
-    else llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, work, pc);
-    const double llp = M.hasPrior ? eval_prior(M, B.x_u, lane) : 0.0;
-    llOut[((size_t)tile * 2) * MCMC_WAVE + lane] = llm;
-    llOut[((size_t)tile * 2 + 1) * MCMC_WAVE + lane] = llp;
+    if constexpr (MULTI) {
+        const int R = M.nRegions, dimR = M.dimRegion;
+        const int waveInBlock = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / MCMC_WAVE));
+        double* slice = lds_raw + (lds_bytes(M, false, T) + 7) / 8 + (size_t)waveInBlock * region_slice_doubles(M);
+        const double* x0_u = B.x_u;
+#pragma unroll 1
+        for (int q = 0; q < R; ++q) {
+            DevModel Mq = M;
+            const LdsView ldsq = stage_region(M, lds, slice, q, lane, Mq.pop);
+            B.x_u = x0_u + (size_t)q * dimR * MCMC_WAVE;
+            LaneScalars lp;
+            load_lane_scalars(M, B.x_u, lane, lp);
+            const double llm = eval_model<T, FUSE, false>(Mq, ldsq, B, lp, lane, work, pc);
+            const double llp = M.hasPrior ? eval_prior(M, B.x_u, lane) : 0.0;
+            llOut[((size_t)tile * 2 * R + 2 * q) * MCMC_WAVE + lane] = llm;
+            llOut[((size_t)tile * 2 * R + 2 * q + 1) * MCMC_WAVE + lane] = llp;
+        }
+    } else {
+        LaneScalars lp;
+        load_lane_scalars(M, B.x_u, lane, lp);
+        double llm;
+        if constexpr (PREC == 1) llm = eval_model_f32<MCMC_TF>(M, lds, B, lp, lane, work, pc);
+        else llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, work, pc);
+        const double llp = M.hasPrior ? eval_prior(M, B.x_u, lane) : 0.0;
+        llOut[((size_t)tile * 2) * MCMC_WAVE + lane] = llm;
+        llOut[((size_t)tile * 2 + 1) * MCMC_WAVE + lane] = llp;
+    }
+}
+
+/* multi-region: the beta slots of every block mirror region 0's (the shared betas) */
+__global__ void mirror_betas_kernel(double* __restrict__ params, long long nP, int R, int dimR, int iBeta) {
+    const long long chain = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (chain >= nP) return;
+    double* x = params + (chain / MCMC_WAVE) * (long long)R * dimR * MCMC_WAVE + chain % MCMC_WAVE;
+    const double bm = x[(long long)iBeta * MCMC_WAVE], bh = x[(long long)(iBeta + 1) * MCMC_WAVE];
+    for (int q = 1; q < R; ++q) {
+        x[((long long)q * dimR + iBeta) * MCMC_WAVE] = bm;
+        x[((long long)q * dimR + iBeta + 1) * MCMC_WAVE] = bh;
+    }
 }
 
 /* derived output coords (covid.h:467-485) of parameter vectors [nTiles][dim][64]:
@@ -1346,10 +1527,12 @@ __global__ __launch_bounds__(MCMC_WAVE) void diagnostics_kernel(DevModel M, Chai
     const long long chain = (long long)tile * MCMC_WAVE + lane;
     const bool live = chain < S.nChains;
     const double* xb = S.params + (size_t)tile * S.dim * MCMC_WAVE;
-    const double* ll_u = S.ll + (size_t)tile * 2 * MCMC_WAVE;
+    const int R = M.nRegions > 1 ? M.nRegions : 1;
+    const double* ll_u = S.ll + (size_t)tile * 2 * R * MCMC_WAVE;
     const double acc = live ? (double)S.nAccept[chain] : 0.0;
     double l = 0;
-    if (live) { l += ll_u[lane]; if (M.hasPrior) l += ll_u[MCMC_WAVE + lane]; }
+    if (live)
+        for (int q = 0; q < R; ++q) { l += ll_u[(2 * q) * MCMC_WAVE + lane]; if (M.hasPrior) l += ll_u[(2 * q + 1) * MCMC_WAVE + lane]; }
     const double sAcc = wave_sum_f64(acc), sL = wave_sum_f64(l), sL2 = wave_sum_f64(l * l);
     if (threadIdx.x == 0) {
         atomicAdd(&out[0], sAcc);

@@ -23,7 +23,8 @@ SYMBOLS = [
     "mcmc_hip_last_error", "mcmc_hip_device_count", "mcmc_host_make_response_tables",
     "mcmc_host_default_disease_params", "mcmc_host_perturb_ics", "mcmc_hip_create",
     "mcmc_hip_destroy", "mcmc_hip_set_tables", "mcmc_hip_set_data", "mcmc_hip_set_precision", "mcmc_hip_set_chains",
-    "mcmc_hip_set_state",
+    "mcmc_hip_set_state", "mcmc_hip_set_regions", "mcmc_hip_n_regions", "mcmc_hip_get_region_loglike",
+    "mcmc_hip_get_region_stepsizes",
     "mcmc_hip_run", "mcmc_hip_step", "mcmc_hip_n_saved", "mcmc_hip_dim", "mcmc_hip_size",
     "mcmc_hip_n_chains", "mcmc_hip_get_params", "mcmc_hip_get_loglike", "mcmc_hip_get_stepsizes",
     "mcmc_hip_get_accept_counts", "mcmc_hip_get_rng_state", "mcmc_hip_get_loglikes",
@@ -82,6 +83,10 @@ def lib():
     L.mcmc_hip_set_data.argtypes = [vp, dp, dp]
     L.mcmc_hip_set_precision.argtypes = [vp, C.c_int32]
     L.mcmc_hip_set_chains.argtypes = [vp, C.c_int64, dp, dp, C.POINTER(C.c_uint64), C.c_uint64]
+    L.mcmc_hip_set_regions.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), dp, dp, dp, dp]
+    L.mcmc_hip_n_regions.argtypes = [vp]
+    L.mcmc_hip_get_region_loglike.argtypes = [vp, dp]
+    L.mcmc_hip_get_region_stepsizes.argtypes = [vp, dp]
     L.mcmc_hip_set_state.argtypes = [vp, C.POINTER(C.c_uint64), dp, dp, C.POINTER(C.c_int32)]
     L.mcmc_hip_run.argtypes = [vp] + [C.c_int32] * 6
     L.mcmc_hip_step.argtypes = [vp, C.c_int32, C.c_double, C.c_int32]
@@ -223,6 +228,7 @@ class CovidSampler:
         self.size = L.mcmc_hip_size(self._h)
         self.n_chains = 0
         self.n_saved = 0
+        self.n_regions = 1
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -241,6 +247,27 @@ class CovidSampler:
         convolution in packed FP32; statistical bar, see include/mcmc_hip.h).  Before set_chains."""
         _check(lib().mcmc_hip_set_precision(self._h, self.PRECISIONS[precision]))
         self.n_chains = 0
+
+    def set_regions(self, cfgs):
+        """multi-region model (extension, BASELINE configs[4]): cfgs = per-region config dicts that differ in
+        deaths, sigma, pop_size, cap0, cap_incr_rate; replaces set_data."""
+        R = len(cfgs)
+        pop = np.ascontiguousarray([int(c["pop_size"]) for c in cfgs], dtype=np.int32)
+        cap0 = np.ascontiguousarray([float(c["cap0"]) for c in cfgs], dtype=np.float64)
+        rate = np.ascontiguousarray([float(c["cap_incr_rate"]) for c in cfgs], dtype=np.float64)
+        deaths = np.ascontiguousarray([c["deaths"] for c in cfgs], dtype=np.float64)
+        sigma = np.ascontiguousarray([c["sigma"] for c in cfgs], dtype=np.float64)
+        _check(lib().mcmc_hip_set_regions(self._h, R, pop.ctypes.data_as(C.POINTER(C.c_int32)), _dp(cap0), _dp(rate),
+                                          _dp(deaths), _dp(sigma)))
+        self.n_regions = R
+        self.dim = lib().mcmc_hip_dim(self._h)
+        self.n_chains = 0
+
+    def region_loglike(self):
+        return self._get("get_region_loglike", (self.n_chains, self.n_regions, 2))
+
+    def region_stepsizes(self):
+        return self._get("get_region_stepsizes", (self.n_chains, self.n_regions))
 
     def set_chains(self, params, stepsizes=None, chain_ids=None, first_chain_id=1):
         params = np.ascontiguousarray(params, dtype=np.float64)

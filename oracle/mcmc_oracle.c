@@ -354,6 +354,12 @@ static double orc_exp(int use_libm, double x) { return use_libm ? exp(x) : mcmc_
 /* covid.h:499-622 (everything before newstate->eval) */
 void orc_covid_propose(const orc_covid_model* m, orc_pcg32* rnd, const double* x,
                        double stepsize, double* xp) {
+    orc_covid_propose_part(m, rnd, x, stepsize, xp, 1);
+}
+/* with_betas = 0 (multi-region extension): a region that does not own the shared betas skips the
+ * betas' branch altogether, gate draw included */
+void orc_covid_propose_part(const orc_covid_model* m, orc_pcg32* rnd, const double* x,
+                            double stepsize, double* xp, int with_betas) {
     const int nB = orc_nb(m), nDisc = m->n_disc, dim = orc_dim(m);
     memcpy(xp, x, sizeof(double) * dim);                            /* covid.h:501 copy() */
     double* behavior = xp;
@@ -374,7 +380,7 @@ void orc_covid_propose(const orc_covid_model* m, orc_pcg32* rnd, const double* x
         if (big1) *delay += (orc_pcg32_next_double(rnd) - 0.5) * sfmin;
         *delay = orc_bound(*delay, 5.0, (double)m->max_delay);
     }
-    if (orc_pcg32_next_float(rnd) < 0.3f) {                         /* covid.h:518-532 */
+    if (with_betas && orc_pcg32_next_float(rnd) < 0.3f) {           /* covid.h:518-532 */
         if (!big2) *betaMild += (orc_pcg32_next_double(rnd) - 0.5) * 0.1 * sfmin;
         else       *betaMild += (orc_pcg32_next_double(rnd) - 0.5) * sfmin;
         *betaMild = orc_bound(*betaMild, 0.0, 100.0);
@@ -558,6 +564,140 @@ int orc_chain_run(const orc_covid_model* m, const orc_target* t, orc_chain* c, i
         }
     }
     if (mean_out)                                                   /* mcmc.h:1133-1134 */
+        for (int k = 0; k < dim; ++k) mean_out[k] *= 1.0 / (nAdjust + nSamples - nBurnin);
+    return n_saved;
+}
+
+/* ------------------------------------------------------- multi-region model ---- */
+/* EXTENSION (BASELINE.json configs[4]; the reference has one region only, covid.h:284-321).
+ * A chain's State is R region blocks [DiseaseSpread_r (, SmoothnessPrior_r)], each a complete
+ * covid.h model with data, population and hospital capacity of its own, all sharing betaMild and
+ * betaHigh, which region 0 owns.  Parameter vector: R blocks of the single-region layout; the beta
+ * slots of every block mirror region 0's.  One MH step moves ONE region, the head, chosen by
+ * systematic scan -- head = (number of random-subspace steps so far) mod R, a given-subspace step
+ * reuses the head -- so the head is the same for every chain and a wavefront never diverges on it:
+ *   - the subspace draw consumes what the single-region State's does (mcmc.h:494-500);
+ *   - DiseaseSpread::step's draws (covid.h:499-622) on the head's block, the betas' branch only for
+ *     region 0;
+ *   - the head is evaluated; if the betas changed, every other region is re-evaluated with them
+ *     (its dependents in the sense of mcmc.h:539-602);
+ *   - delta = sum over the evaluated likelihoods in State order (DS_0, P_0, DS_1, P_1, ...) of
+ *     (-old + new) (mcmc.h:604-606), accept as in Target::step (mcmc.h:762-781);
+ *   - the adjust phase corrects the head's own stepsizeCorrectionFac (mcmc.h:1107-1114).
+ * With R = 1 this is orc_chain_step / orc_chain_run exactly. */
+void orc_multi_init(const orc_covid_model* regs, int R, orc_multi_chain* c, int chain_id, const double* x0,
+                    double stepsize) {
+    const int dimR = orc_dim(&regs[0]), nB = orc_nb(&regs[0]), nDisc = regs[0].n_disc;
+    memset(c, 0, sizeof(*c));
+    orc_pcg32_seed(&c->rng, 0, (uint64_t)chain_id);
+    c->x = (double*)malloc(sizeof(double) * dimR * R);
+    c->xp = (double*)malloc(sizeof(double) * dimR);
+    c->ll = (double*)calloc((size_t)2 * R, sizeof(double));
+    c->llp = (double*)calloc((size_t)R, sizeof(double));
+    c->stepsize = (double*)malloc(sizeof(double) * R);
+    memcpy(c->x, x0, sizeof(double) * dimR * R);
+    for (int r = 0; r < R; ++r) {
+        c->stepsize[r] = stepsize;
+        c->x[r * dimR + nB + nDisc] = c->x[nB + nDisc];             /* the shared betas are region 0's */
+        c->x[r * dimR + nB + nDisc + 1] = c->x[nB + nDisc + 1];
+        c->ll[2 * r] = orc_covid_eval(&regs[r], c->x + r * dimR, NULL, 0);
+        c->ll[2 * r + 1] = regs[r].has_prior ? orc_smooth_eval(c->x + r * dimR, nB, regs[r].smooth_Ls, regs[r].smooth_L) : 0.0;
+    }
+}
+void orc_multi_free(orc_multi_chain* c) {
+    free(c->x); free(c->xp); free(c->ll); free(c->llp); free(c->stepsize);
+    memset(c, 0, sizeof(*c));
+}
+
+int orc_multi_step(const orc_covid_model* regs, int R, const orc_target* t, orc_multi_chain* c, double time,
+                   int random_subspace) {
+    const orc_covid_model* m0 = &regs[0];
+    const int dimR = orc_dim(m0), nB = orc_nb(m0), nDisc = m0->n_disc;
+    const int nState = m0->has_prior ? 2 : 1;
+    if (random_subspace) {
+        size_t head;
+        do {                                                        /* mcmc.h:494-500, as orc_chain_step */
+            float f = orc_pcg32_next_float(&c->rng) * nState;
+            head = (size_t)f;
+            if (head > (size_t)(nState - 1)) head = nState - 1;
+        } while (head != 0);
+        c->head = (int)(c->head_counter % (uint64_t)R);             /* systematic scan over the regions */
+        c->head_counter++;
+    }
+    const int h = c->head;
+    double* xh = c->x + (size_t)h * dimR;
+    orc_covid_propose_part(&regs[h], &c->rng, xh, c->stepsize[h], c->xp, h == 0);
+    const double bm = c->xp[nB + nDisc], bh = c->xp[nB + nDisc + 1];
+    const int all = (bm != xh[nB + nDisc]) || (bh != xh[nB + nDisc + 1]);
+    double llpH = 0.0, delta = 0;
+    double* tmp = (double*)malloc(sizeof(double) * dimR);
+    for (int q = 0; q < R; ++q) {                                   /* State order */
+        if (q != h && !all) continue;
+        double llq;
+        if (q == h) {
+            llq = orc_covid_eval(&regs[q], c->xp, NULL, 0);
+        } else {                                                    /* a dependent: its own coords, the new betas */
+            memcpy(tmp, c->x + (size_t)q * dimR, sizeof(double) * dimR);
+            tmp[nB + nDisc] = bm; tmp[nB + nDisc + 1] = bh;
+            llq = orc_covid_eval(&regs[q], tmp, NULL, 0);
+        }
+        c->llp[q] = llq;
+        delta += -c->ll[2 * q] + llq;
+        if (q == h && m0->has_prior) {
+            llpH = orc_smooth_eval(c->xp, nB, regs[h].smooth_Ls, regs[h].smooth_L);
+            delta += -c->ll[2 * h + 1] + llpH;
+        }
+    }
+    free(tmp);
+    delta += (log(1.0) - log(1.0));
+    delta *= orc_target_beta(t, time);
+    c->n_steps++;
+    int acc = 0;
+    if ((double)orc_pcg32_next_float(&c->rng) < 1.0 * orc_exp(m0->use_libm, delta)) {
+        memcpy(xh, c->xp, sizeof(double) * dimR);
+        for (int q = 0; q < R; ++q) {
+            if (q != h && !all) continue;
+            c->ll[2 * q] = c->llp[q];
+            c->x[(size_t)q * dimR + nB + nDisc] = bm;
+            c->x[(size_t)q * dimR + nB + nDisc + 1] = bh;
+        }
+        if (m0->has_prior) c->ll[2 * h + 1] = llpH;
+        c->n_accept++;
+        acc = 1;
+    }
+    return acc;
+}
+
+int orc_multi_run(const orc_covid_model* regs, int R, const orc_target* t, orc_multi_chain* c, int nSamples,
+                  int nBurnin, int nAdjust, int thinning, double* loglikes_out, double* samples_out, double* mean_out) {
+    const int dim = orc_dim(&regs[0]) * R;
+    int n_saved = 0;
+    c->n_accept = 0;
+    if (mean_out) memcpy(mean_out, c->x, sizeof(double) * dim);
+    for (int i = 0; i < nSamples + nAdjust; ++i) {                  /* mcmc.h:1023, as orc_chain_run */
+        if (i == nAdjust) c->n_accept = 0;
+        if ((i >= nBurnin) && (i % thinning) == 0) {
+            double time = (i < nAdjust) ? (double)i / nAdjust : (double)(i - nAdjust) / nSamples;
+            double ll = 0;
+            for (int q = 0; q < R; ++q) { ll += c->ll[2 * q]; if (regs[0].has_prior) ll += c->ll[2 * q + 1]; }
+            if (loglikes_out) loglikes_out[n_saved] = log(1.0) + orc_target_beta(t, time) * ll;
+            if (samples_out) memcpy(samples_out + (size_t)n_saved * dim, c->x, sizeof(double) * dim);
+            ++n_saved;
+        }
+        if ((i > nBurnin) && mean_out)
+            for (int k = 0; k < dim; ++k) mean_out[k] += c->x[k];
+        if (i < nAdjust) {
+            double time = (double)i / nAdjust;
+            c->n_accept = 0;
+            orc_multi_step(regs, R, t, c, time, 1);
+            const int nRepeat = 20;
+            for (int j = 0; j < nRepeat - 1; ++j) orc_multi_step(regs, R, t, c, time, 0);
+            c->stepsize[c->head] *= rate2corr((double)c->n_accept / nRepeat);
+        } else {
+            orc_multi_step(regs, R, t, c, (double)(i - nAdjust) / nSamples, 1);
+        }
+    }
+    if (mean_out)
         for (int k = 0; k < dim; ++k) mean_out[k] *= 1.0 / (nAdjust + nSamples - nBurnin);
     return n_saved;
 }

@@ -128,6 +128,8 @@ double orc_smooth_eval(const double* f, int n, double Ls, double L);
 /* DiseaseSpread::step proposal part (covid.h:499-622): x -> xp, draws from rng */
 void   orc_covid_propose(const orc_covid_model* m, orc_pcg32* rng, const double* x,
                          double stepsize, double* xp);
+void   orc_covid_propose_part(const orc_covid_model* m, orc_pcg32* rng, const double* x,
+                              double stepsize, double* xp, int with_betas);
 /* DiseaseSpread::force_bounds (covid.h:629-646) */
 void   orc_covid_force_bounds(const orc_covid_model* m, double* x);
 
@@ -165,6 +167,26 @@ int  orc_chain_run(const orc_covid_model* m, const orc_target* t, orc_chain* c,
                    int nSamples, int nBurnin, int nAdjust, int thinning,
                    double* loglikes_out, double* samples_out, double* mean_out);
 int  orc_n_saved(int nSamples, int nBurnin, int nAdjust, int thinning);
+
+/* ---- multi-region model (EXTENSION, BASELINE.json configs[4]; definition in mcmc_oracle.c) ----
+ * regs [R]: complete models that differ in deaths, sigma, pop_size, cap0, cap_incr_rate only.
+ * x [R][dimRegion] blocks of the single-region layout; ll [R][2] = (model, prior) per region. */
+typedef struct {
+    orc_pcg32 rng;
+    double* x;          /* [R * dimRegion] */
+    double* xp;         /* [dimRegion] the head's proposal */
+    double* ll;         /* [R][2] */
+    double* llp;        /* [R] scratch: proposed model log-likelihoods */
+    double* stepsize;   /* [R] stepsizeCorrectionFac of every region's DiseaseSpread */
+    int n_accept;
+    uint64_t n_steps, head_counter;
+    int head;
+} orc_multi_chain;
+void orc_multi_init(const orc_covid_model* regs, int R, orc_multi_chain* c, int chain_id, const double* x0, double stepsize);
+void orc_multi_free(orc_multi_chain* c);
+int  orc_multi_step(const orc_covid_model* regs, int R, const orc_target* t, orc_multi_chain* c, double time, int random_subspace);
+int  orc_multi_run(const orc_covid_model* regs, int R, const orc_target* t, orc_multi_chain* c, int nSamples, int nBurnin,
+                   int nAdjust, int thinning, double* loglikes_out, double* samples_out, double* mean_out);
 
 /* many chains on a thread pool (ChainManager::run_all_adjust, mcmc.h:1513-1553);
  * chain i uses pcg32(0, i+1) (mcmc.h:1527).  x is [n_chains][dim] in/out; returns wall s

@@ -66,6 +66,12 @@ class Chain(C.Structure):
                 ("last_accept", C.c_int), ("grid_own", C.POINTER(C.c_double))]
 
 
+class MultiChainC(C.Structure):
+    _fields_ = [("rng", Pcg32), ("x", C.POINTER(C.c_double)), ("xp", C.POINTER(C.c_double)),
+                ("ll", C.POINTER(C.c_double)), ("llp", C.POINTER(C.c_double)), ("stepsize", C.POINTER(C.c_double)),
+                ("n_accept", C.c_int), ("n_steps", C.c_uint64), ("head_counter", C.c_uint64), ("head", C.c_int)]
+
+
 _lib = None
 
 
@@ -117,6 +123,12 @@ def lib():
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp,
                                  C.POINTER(C.c_int), C.POINTER(C.c_uint64), dp]
     L.orc_run_chains.restype = C.c_double
+    L.orc_multi_init.argtypes = [C.POINTER(CovidModel), C.c_int, C.POINTER(MultiChainC), C.c_int, dp, C.c_double]
+    L.orc_multi_free.argtypes = [C.POINTER(MultiChainC)]
+    L.orc_multi_step.argtypes = [C.POINTER(CovidModel), C.c_int, C.POINTER(Target), C.POINTER(MultiChainC), C.c_double, C.c_int]
+    L.orc_multi_step.restype = C.c_int
+    L.orc_multi_run.argtypes = [C.POINTER(CovidModel), C.c_int, C.POINTER(Target), C.POINTER(MultiChainC)] + [C.c_int] * 4 + [dp, dp, dp]
+    L.orc_multi_run.restype = C.c_int
     L.orc_mylike1_run.argtypes = [C.c_int] * 5 + [dp, dp, dp, C.POINTER(C.c_int), dp]
     L.orc_mylike1_run.restype = C.c_int
     L.orc_fourgauss_run.argtypes = [C.c_double, C.c_double, C.c_int, dp] + [C.c_int] * 4 + \
@@ -324,3 +336,59 @@ def rosenbrock_run(difficulty, T, chain_id, x0, nSamples, nBurnin, nAdjust, thin
     lib().orc_rosenbrock_run(difficulty, T, chain_id, _dp(x0), nSamples, nBurnin, nAdjust, thinning,
                              _dp(ll), _dp(s), C.byref(sf), C.byref(na), _dp(mean), stepsize)
     return (ll, s, sf.value, na.value, mean) if with_mean else (ll, s, sf.value, na.value)
+
+
+class MultiModel:
+    """R region models (extension, BASELINE configs[4]): cfgs is a list of per-region config dicts that differ
+    in deaths, sigma, pop_size, cap0, cap_incr_rate only."""
+
+    def __init__(self, cfgs, R11, contract=0):
+        self.models = [Model(c, R11, contract=contract) for c in cfgs]
+        self.R = len(cfgs)
+        self.arr = (CovidModel * self.R)(*[m.m for m in self.models])
+        self.dim_region = self.models[0].dim
+        self.dim = self.dim_region * self.R
+
+
+class MultiChain:
+    def __init__(self, mm: MultiModel, chain_id, x0, stepsize=1.0):
+        self.mm = mm
+        self.c = MultiChainC()
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        assert x0.shape == (mm.dim,)
+        lib().orc_multi_init(mm.arr, mm.R, C.byref(self.c), chain_id, _dp(x0), stepsize)
+
+    def step(self, target, time=0.0, random_subspace=True):
+        return lib().orc_multi_step(self.mm.arr, self.mm.R, C.byref(target), C.byref(self.c), time, 1 if random_subspace else 0)
+
+    def run(self, target, nSamples, nBurnin, nAdjust, thinning, record=True, mean=False):
+        n = lib().orc_n_saved(nSamples, nBurnin, nAdjust, thinning)
+        ll = np.zeros(n)
+        samples = np.zeros((n, self.mm.dim)) if record else None
+        mu = np.zeros(self.mm.dim) if mean else None
+        got = lib().orc_multi_run(self.mm.arr, self.mm.R, C.byref(target), C.byref(self.c), nSamples, nBurnin, nAdjust,
+                                  thinning, _dp(ll), _dp(samples), _dp(mu))
+        assert got == n
+        return ll, samples, mu
+
+    @property
+    def x(self):
+        return np.ctypeslib.as_array(self.c.x, shape=(self.mm.dim,)).copy()
+
+    @property
+    def ll(self):
+        return np.ctypeslib.as_array(self.c.ll, shape=(self.mm.R, 2)).copy()
+
+    @property
+    def stepsizes(self):
+        return np.ctypeslib.as_array(self.c.stepsize, shape=(self.mm.R,)).copy()
+
+    @property
+    def rng_state(self):
+        return (self.c.rng.state, self.c.rng.inc)
+
+    def __del__(self):
+        try:
+            lib().orc_multi_free(C.byref(self.c))
+        except Exception:
+            pass

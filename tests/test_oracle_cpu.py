@@ -518,3 +518,32 @@ def test_toy_rosenbrock_oracle_moments():
     x = np.array([0.3, -0.7])
     assert O.lib().orc_rosenbrock_eval(100.0, x.ctypes.data_as(O.C.POINTER(O.C.c_double))) == \
         -((1 - 0.3) * (1 - 0.3) + 100.0 * ((-0.7 - 0.3 * 0.3) * (-0.7 - 0.3 * 0.3))) / 20
+
+
+def test_multi_region_oracle_reduces_to_the_single_region_chain(R11):
+    """orc_multi_* (extension, BASELINE configs[4]) with one region IS orc_chain_*; with three regions the
+    betas stay shared, every region's log-likelihood is the stand-alone model's at its block, and the scan
+    visits the regions in turn."""
+    cfg = make_cfg(40, R11, max_delay=12, n_predict=5, fix_behavior_in_advance=5, initial_delay=7.0)
+    x0 = perturbed(cfg, 1, 0.05)[0]
+    tgt = O.make_target("temp", 1.0)
+    a = O.MultiChain(O.MultiModel([cfg], R11), 3, x0)
+    b = O.OracleChain(O.Model(cfg, R11), 3, x0)
+    ra, rb = a.run(tgt, 30, 2, 3, 2, mean=True), b.run(tgt, 30, 2, 3, 2, mean=True)
+    assert all(np.array_equal(u, v) for u, v in zip(ra, rb))
+    assert a.rng_state == b.rng_state and np.array_equal(a.x, b.x) and a.stepsizes[0] == b.c.stepsize
+    cfgs = [cfg, dict(cfg, pop_size=30000000, cap0=3000.0), dict(cfg, deaths=cfg["deaths"] * 1.3, sigma=cfg["sigma"] * 1.1)]
+    mm = O.MultiModel(cfgs, R11)
+    x3 = np.concatenate([perturbed(cfg, 1, 0.05, seq=k)[0] for k in range(3)])
+    c = O.MultiChain(mm, 5, x3)
+    dimR, iB = cfg["dim"], cfg["nB"] + cfg["n_disc"]
+    heads = []
+    for _ in range(90):
+        c.step(tgt)
+        heads.append(c.c.head)
+        blocks = c.x.reshape(3, dimR)
+        assert np.all(blocks[:, iB] == blocks[0, iB]) and np.all(blocks[:, iB + 1] == blocks[0, iB + 1])
+        for q in range(3):
+            assert c.ll[q, 0] == mm.models[q].eval(blocks[q]) and c.ll[q, 1] == mm.models[q].prior(blocks[q])
+    assert heads[:7] == [0, 1, 2, 0, 1, 2, 0] and c.c.n_accept > 10
+    assert c.x.reshape(3, dimR)[0, iB] != x3[iB]

@@ -18,9 +18,9 @@ def analyse(workdir):
     asm = open(os.path.join(workdir, "mcmc_hip-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     out = {}
     # (mangled-name prefix, instruction prefixes counted as work, {work per iteration: loop name})
-    kernels = [("_Z14mh_step_kernelILi8ELb1ELi0EE", ("v_fmac_f64", "v_fma_f64", "v_add_f64"),
+    kernels = [("_Z14mh_step_kernelILi8ELb1ELi0ELb0EE", ("v_fmac_f64", "v_fma_f64", "v_add_f64"),
                 {896: "plain_loop", 1408: "eterm_loop"}),
-               ("_Z14mh_step_kernelILi8ELb1ELi1EE", ("v_pk_fma_f32",),       # fast mode, mcmc_model_f32.hip.h
+               ("_Z14mh_step_kernelILi8ELb1ELi1ELb0EE", ("v_pk_fma_f32",),       # fast mode, mcmc_model_f32.hip.h
                 {512: "fast_plain_loop", 768: "fast_eterm_loop"})]
     for sym, ops, names in kernels:
         m = re.search(r"^" + sym + r"[^\n]*:.*?\.end_amdhsa_kernel", asm, re.S | re.M)
@@ -46,7 +46,7 @@ def analyse(workdir):
             out[name] = {"instructions": len(ins), "ops": fma, "scratch": sum("scratch" in t for t in ins),
                          "sgpr_spill_moves": sum(t.startswith(("v_readlane", "v_writelane")) for t in ins),
                          "min_vmcnt": min(waits) if waits else None}
-        if sym.endswith("Li0EE"):
+        if sym.endswith("Li0ELb0EE"):
             m0 = m
     m = m0
     vg = re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(0))
