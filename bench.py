@@ -67,6 +67,33 @@ def build_workload(device, n_chains, first_chain_id, contract, n_data=N_DATA, pr
     return cfg, R, xs, sampler
 
 
+def build_region_workload(device, n_chains, first_chain_id, contract, n_regions, n_data):
+    """BASELINE.json configs[4] (extension, include/mcmc_hip.h at mcmc_hip_set_regions): n_regions regions per
+    chain over a long horizon (n_data days; maxDelay 40 + nPredict 60 on top: beyond the 500-day response
+    table), each a complete DiseaseSpread block -- three behaviour nodes, one breakpoint value, its delay --
+    plus the two shared betas.  Regions differ in population and hospital capacity; their counts come from
+    the forward model at their own constants."""
+    dp = CC.ipynb_disease_params()
+    R = H.make_response_tables(dp)
+    kw = dict(disease_params=dp, initial_beta_mild=BETA_MILD, initial_beta_high=BETA_HIGH, contract=contract,
+              fix_behavior_in_advance=n_data - 3, disc_days=(20,), disc_vals=(0.6,))
+
+    def forward(cfg, x):
+        s = H.CovidSampler(cfg, R, device)
+        dead = s.derive(x[None, :])[0, 7]
+        s.close()
+        return dead
+
+    cfgs = [CC.synthetic_config(n_data, forward, pop_size=int(6e7 / (1 + 0.25 * (r % 8))), cap0=7500.0 / (1 + r % 5),
+                                cap_incr_rate=100.0 - r % 50, **kw) for r in range(n_regions)]
+    x0 = np.concatenate([CC.initial_params(c) for c in cfgs])
+    xs = H.perturb_ics(x0, first_chain_id - 1 + n_chains, 0.01)[first_chain_id - 1:]
+    sampler = H.CovidSampler(cfgs[0], R, device)
+    sampler.set_regions(cfgs)
+    sampler.set_chains(xs, first_chain_id=first_chain_id)
+    return cfgs, R, xs, sampler
+
+
 def host_threads():
     """Threads of the CPU leg: the cores this process may run on, capped by the box's per-GPU CPU
     share (the GPU box exports OMP_NUM_THREADS = 16 for a one-GPU slot of a much larger machine and
@@ -201,6 +228,9 @@ def main():
     ap.add_argument("--ladder", type=int, default=0, help="temperatures per ladder (0: no tempering)")
     ap.add_argument("--ladder-tmax", type=float, default=16.0)
     ap.add_argument("--swap-every", type=int, default=8, help="MH steps between exchange rounds")
+    # BASELINE.json configs[4] (extension): multi-region model, e.g. --regions 50 --chains-per-gpu 131072
+    ap.add_argument("--regions", type=int, default=0, help="regions per chain (0: the single-region headline workload)")
+    ap.add_argument("--region-days", type=int, default=500, help="data days of the multi-region workload")
     # rehearsal knobs: several ranks on ONE card need the gloo backend and a fixed device
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--device", type=int, default=None, help="HIP ordinal for every rank (default: LOCAL_RANK)")
@@ -234,7 +264,16 @@ def main():
 
     n_chains = args.chains_per_gpu
     first_id = 1 + rank * n_chains                       # contiguous chain-id ranges
-    cfg, R, xs, s = build_workload(device, n_chains, first_id, args.contract, precision=args.precision)
+    n_data = N_DATA
+    if args.regions:
+        if args.ladder or args.precision != "f64":
+            raise SystemExit("bench.py: --regions runs without --ladder, in f64")
+        n_data = args.region_days
+        cfgs, R, xs, s = build_region_workload(device, n_chains, first_id, args.contract, args.regions, n_data)
+        cfg = dict(cfgs[0])
+        cfg["dim"] = s.dim
+    else:
+        cfg, R, xs, s = build_workload(device, n_chains, first_id, args.contract, precision=args.precision)
     fast_main = args.precision != "f64"
     peak = PEAK_FP32_VECTOR_TFLOPS if fast_main else PEAK_FP64_VECTOR_TFLOPS
 
@@ -250,7 +289,7 @@ def main():
         temps = np.geomspace(1.0, args.ladder_tmax, args.ladder)
         s.set_ladder(temps, swap_seed=1, first_ladder=rank * (n_chains // args.ladder))
     s.step(args.warmup, 1.0, True)
-    adapted = (s.params(), s.stepsizes())                # start of the CPU leg and the side legs
+    adapted = (s.params(), s.stepsizes()) if not args.regions else None   # start of the CPU leg and the side legs
     s.pair_count(reset=True)
     t_before = s.last_timing()
     diag_before = s.diagnostics()                        # additive sums of this shard (untimed)
@@ -279,7 +318,7 @@ def main():
 
     # ESS / R-hat leg on every rank (its first --ess-chains chains), pieces summed by one more all-reduce
     ess_tot = None
-    if args.ess_chains > 0 and not args.ladder and not fast_main:
+    if args.ess_chains > 0 and not args.ladder and not fast_main and not args.regions:
         ne = min(args.ess_chains, n_chains)
         pieces, ess_saved = ess_leg(cfg, R, device, args.contract, adapted[0][:ne], adapted[1][:ne], first_id,
                                     args.ess_steps, 5)
@@ -294,7 +333,7 @@ def main():
         pairs = s.pair_count()                            # sum over chains/steps, SURVEY 8d work unit
         pairs_exec = s.executed_pair_count()
         nB = cfg["nB"]
-        flops = 16.0 * pairs + (10.0 * N_DATA + 7.0 * nB) * n_chains * args.steps
+        flops = 16.0 * pairs + (10.0 * n_data + 7.0 * nB) * n_chains * args.steps
         flops_exec = 14.0 * pairs_exec                    # the multiply-adds the kernel ran: 7 families, visible days
         achieved = flops / ksec / 1e12
         # HBM-side traffic: not measured in this run (PMC counters need rocprofv3); taken from the
@@ -318,9 +357,13 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 packed (renewal convolution) + f64 -- FAST MODE, not the headline metric" if fast_main else "f64",
             "data": "synthetic",
-            "config": {"workload": f"covid.h model, {n_chains} independent chains per GPU, 365-day synthetic "
-                                   "series, chain-sharded (BASELINE.json configs[2])",
-                       "chains_per_gpu": n_chains, "n_data": N_DATA, "dim": cfg["dim"],
+            "config": {"workload": (f"multi-region covid.h model (extension), {args.regions} regions x {n_data} data days, "
+                                    f"{n_chains} independent chains per GPU, systematic scan over the regions, chain-sharded "
+                                    "(BASELINE.json configs[4]) -- NOT the headline workload") if args.regions else
+                                   (f"covid.h model, {n_chains} independent chains per GPU, 365-day synthetic "
+                                    "series, chain-sharded (BASELINE.json configs[2])"),
+                       **({"regions": args.regions, "dim_per_region": cfgs[0]["dim"]} if args.regions else {}),
+                       "chains_per_gpu": n_chains, "n_data": n_data, "dim": cfg["dim"],
                        "size": cfg["size"], "fp_contract": "fma" if args.contract else "strict",
                        "adjust_iterations_before_timing": args.adjust,
                        **({"ladder": {"temperatures": args.ladder, "t_max": args.ladder_tmax,
@@ -341,6 +384,10 @@ def main():
                                               "the log-likelihood can see); capacity corrections, proposal and the "
                                               "sequential day loop not counted"}},
         }
+        if args.regions:
+            out["metric"] = "MH steps/sec on the multi-region covid model (extension leg, BASELINE.json configs[4])"
+            out["roofline"]["traffic"] = None
+            out["roofline"]["traffic_source"] = None
         n_all, dim = tot[1], cfg["dim"]
 
         def mean_sd(k):                                   # cross-chain mean / sd from (sum x, sum x^2)
@@ -352,11 +399,11 @@ def main():
                               "how": f"mcmc_hip_diagnostics per rank, one all-reduce(SUM) of {len(local)} doubles "
                                      f"({'RCCL' if (dist is not None and args.backend == 'nccl') else 'single rank' if dist is None else 'gloo'})"}
         n_keep = max(256, min(4096, n_chains))
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.regions:
             cb = cpu_baseline(cfg, R, adapted[0][:n_keep], adapted[1][:n_keep], args.contract)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = value / cb["value"]
-        side = world == 1 and not args.ladder and not fast_main
+        side = world == 1 and not args.ladder and not fast_main and not args.regions
         if side and args.contract and not args.no_strict_leg:
             # the C++ source semantics: every projection term a multiply and an add (cfg.contract = 0)
             out["strict"] = side_leg(cfg, R, device, adapted, first_id, args, "f64", 0)

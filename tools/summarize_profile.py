@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise a tools/profile_gpu.sh output directory (gpurun_out/prof_<tag>) into
 profiles/<round>/<tag>_*.{csv,txt,json} and profiles/traffic_latest.json.
-usage: summarize_profile.py gpurun_out/prof_<tag> profiles/r01 <tag>"""
+usage: summarize_profile.py gpurun_out/prof_<tag> profiles/r02 <tag>"""
 import collections, csv, glob, json, os, shutil, sys
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dst, exist_ok=True)
@@ -47,6 +47,7 @@ with open(os.path.join(dst, f"{tag}_pmc_summary.txt"), "w") as o:
         write = mean["WRITE_SIZE"] * 1024
         o.write(f"HBM-side bytes per launch: fetch {fetch:.4g} (FETCH_SIZE KB x 1024 x 2, gfx950 correction) + write {write:.4g}\n")
         json.dump({"hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "tag": tag,
+                   "chains": bench["config"]["chains_per_gpu"], "steps_per_launch": 16,
                    "note": "FETCH_SIZE x2 (gfx950 under-count of wide coalesced reads) + WRITE_SIZE, per mh_step_kernel launch of 16 steps x 65536 chains"},
                   open(os.path.join(os.path.dirname(dst.rstrip('/')),
                                     "traffic_fast_mode.json" if "fast" in tag else "traffic_latest.json"), "w"))
