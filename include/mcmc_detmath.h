@@ -77,25 +77,26 @@ MCMC_HD double mcmc_cos(double x) {
     const double p1  = 1.57079632673412561417e+00;  /* first 33 bits of pi/2 */
     const double p2  = 6.07710050630396597660e-11;  /* next 33 bits */
     const double p2t = 2.02226624879595063154e-21;  /* pi/2 - p1 - p2 */
-    double ax = x < 0 ? -x : x;
-    if (!(ax < 1.0e300)) return x - x;   /* inf or nan -> nan (huge finite: garbage-in) */
-    if (ax <= 0.78539816339744827900) return mcmc_kcos(x, 0.0);
-    double fn = mcmc_rint_small(ax * invpio2);
+    /* Straight-line on purpose: on the GPU 64 chains evaluate this in lockstep with arguments in
+     * every quadrant, so each data-dependent branch is executed by the whole wave anyway, plus the
+     * exec-mask bookkeeping around it.  Both kernels are evaluated and the quadrant selects.
+     * (|x| <= pi/4 needs no case of its own: there fn = 0, the reduction returns (ax, 0) exactly
+     * and quadrant 0 evaluates kcos(ax, 0) = kcos(x, 0).) */
+    const double ax = x < 0 ? -x : x;
+    const double fn = mcmc_rint_small(ax * invpio2);
     /* two-stage Cody-Waite reduction, always both stages: fixed operation count.
      * pi/2 = p1 + p2 + p2t to ~118 bits; fn*p1 and fn*p2 are exact for fn < 2^20. */
-    double t = ax - fn * p1;
+    const double t = ax - fn * p1;
     double w = fn * p2;
-    double r = t - w;
+    const double r = t - w;
     w = fn * p2t - ((t - r) - w);
-    double y0 = r - w;
-    double y1 = (r - y0) - w;
-    int64_t n = (int64_t)fn;
-    switch (n & 3) {
-        case 0:  return  mcmc_kcos(y0, y1);
-        case 1:  return -mcmc_ksin(y0, y1);
-        case 2:  return -mcmc_kcos(y0, y1);
-        default: return  mcmc_ksin(y0, y1);
-    }
+    const double y0 = r - w;
+    const double y1 = (r - y0) - w;
+    const int64_t n = (ax < 1.0e300) ? (int64_t)fn : 0;
+    const double c = mcmc_kcos(y0, y1), s = mcmc_ksin(y0, y1);
+    double v = (n & 1) ? s : c;                      /* quadrants 0..3: c, -s, -c, s */
+    v = ((n + 1) & 2) ? -v : v;
+    return (ax < 1.0e300) ? v : x - x;               /* inf or nan -> nan (huge finite: garbage-in, 0) */
 }
 
 /*

@@ -1069,11 +1069,11 @@ __device__ inline bool propose(const DevModel& M, Pcg32& rnd, const double* __re
             for (int j = 0; j < PB; ++j) {
                 const int i = i0 + j;
                 if (i < n) {
-                    double v = vv[j];
-                    if (doB) {
-                        v += A * (mcmc_cos(omega * (double)i) - 1);
-                        v = bound_reflect(v, 0.0, 2.0);
-                    }
+                    /* straight-line: the lanes that do not move their behaviour function compute a value
+                     * too (omega = A = 0) and keep the old one -- cheaper for the wave than a per-lane
+                     * branch around ~60 double-precision operations */
+                    const double moved = bound_reflect(vv[j] + A * (mcmc_cos(omega * (double)i) - 1), 0.0, 2.0);
+                    const double v = doB ? moved : vv[j];
                     xp_u[i * MCMC_WAVE + lane] = v;
                     if (i >= 2) {
                         const double dd = v + fm - 2 * f0;

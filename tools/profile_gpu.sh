@@ -9,7 +9,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-args="--no-cpu-baseline --ess-chains 0 --no-fast-leg $*"
+args="--no-cpu-baseline --ess-chains 0 --no-fast-leg --no-strict-leg $*"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 "$root/bench.py" $args > "$out/bench_stats.json" 2> "$out/stats.err" || { echo "stats pass failed"; tail -5 "$out/stats.err"; exit 1; }
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU" "TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo "$pass" | cut -d' ' -f1)
