@@ -303,6 +303,15 @@ int mcmc_hip_toy_run(int device, int32_t kind, double difficulty, int32_t target
  * log-likelihood, prior, accept, record, lag chunks with e-terms.  All zeros unless the library was built with
  * -DMCMC_STAMPS (the stamps cost a few per cent). */
 int mcmc_hip_debug_phase_cycles(mcmc_hip_ctx* ctx, double* out, int32_t reset);
+/* Diagnostic (no counterpart in the reference; -DMCMC_STAMPS builds): per tile of the last launch, the
+ * wave's shader cycles, (XCC_ID << 32) | HW_ID of where it ran, its lag chunks with e-terms, the days on which
+ * any of its chains had a capacity correction and the length of the day range spanning them (summed over
+ * the launch's evaluations); n <= 8192. */
+int mcmc_hip_debug_wave_log(mcmc_hip_ctx* ctx, double* cycles, uint64_t* hwid, double* e_chunks, double* e_days,
+                            double* e_hull, int64_t n);
+/* Diagnostic (no counterpart in the reference; -DMCMC_F32_CHECK builds of the fast mode): out[4] = kind of the
+ * first row range that fell outside its buffer (0: none), its low and high row and the buffer's rows. */
+int mcmc_hip_debug_f32_check(mcmc_hip_ctx* ctx, int32_t* out);
 
 #ifdef __cplusplus
 }

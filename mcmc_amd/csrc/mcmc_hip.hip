@@ -1197,6 +1197,31 @@ int mcmc_hip_debug_phase_cycles(mcmc_hip_ctx* c, double* out, int32_t reset) try
     return 0;
 } MCMC_ABI_GUARD
 
+/* -DMCMC_F32_CHECK builds of the fast mode: out[4] = kind (0: no violation), low row, high row, bound of the
+ * first row range that fell outside its buffer (mcmc_model_f32.hip.h) */
+int mcmc_hip_debug_f32_check(mcmc_hip_ctx* c, int32_t* out) try {
+    if (int r = check_ctx(c)) return r;
+    if (!out) return fail(MCMC_HIP_EINVAL, "null output buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f32_check), 4 * sizeof(int)));
+    return 0;
+} MCMC_ABI_GUARD
+
+/* -DMCMC_STAMPS builds: per tile of the last launch, the wave's cycles, its (XCC_ID << 32 | HW_ID), its lag chunks
+ * with e-terms, the days on which any lane had a capacity correction and the length of their hull */
+int mcmc_hip_debug_wave_log(mcmc_hip_ctx* c, double* cycles, uint64_t* hwid, double* e_chunks, double* e_days, double* e_hull, int64_t n) try {
+    if (int r = check_ctx(c)) return r;
+    if (!cycles || !hwid || !e_chunks || !e_days || !e_hull || n < 0 || n > MCMC_WAVE_LOG) return fail(MCMC_HIP_EINVAL, "wave log: bad arguments (at most %d tiles)", MCMC_WAVE_LOG);
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<unsigned long long> h(4 * MCMC_WAVE_LOG);
+    HIP_TRY(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_wave_log), h.size() * sizeof(unsigned long long)));
+    for (int64_t i = 0; i < n; ++i) {
+        cycles[i] = (double)h[4 * i]; hwid[i] = h[4 * i + 1]; e_chunks[i] = (double)h[4 * i + 2];
+        e_days[i] = (double)(h[4 * i + 3] >> 32); e_hull[i] = (double)(h[4 * i + 3] & 0xffffffffull);
+    }
+    return 0;
+} MCMC_ABI_GUARD
+
 /* sums one of the two per-chain work counters ([nTiles][2][64]: algorithmic, executed) */
 static int work_count(mcmc_hip_ctx* c, int which, double* out, int32_t reset) {
     if (int r = need_chains(c, out)) return r;

@@ -130,8 +130,10 @@ __device__ __forceinline__ double madd(double a, double b, double c) {
 /* Built with -DMCMC_STAMPS the kernels accumulate, per phase of an MH step, the shader
  * cycles (s_memtime) every wave spends there into g_phase_cycles; mcmc_hip_debug_phase_cycles
  * reads them.  Without the macro the hooks compile to nothing. */
-enum { PH_PROPOSE = 0, PH_SETUP, PH_CHUNKS, PH_TAIL, PH_DAYS, PH_LOGLIKE, PH_PRIOR, PH_ACCEPT, PH_RECORD, PH_CHUNKS_E, PH_NCHUNK, PH_NCHUNK_E, PH_WAIT, PH_COUNT };
+enum { PH_PROPOSE = 0, PH_SETUP, PH_CHUNKS, PH_TAIL, PH_DAYS, PH_LOGLIKE, PH_PRIOR, PH_ACCEPT, PH_RECORD, PH_CHUNKS_E, PH_NCHUNK, PH_NCHUNK_E, PH_WAIT, PH_EDAYS, PH_EHULL, PH_COUNT };
 __device__ unsigned long long g_phase_cycles[16];
+#define MCMC_WAVE_LOG 8192            /* tiles the -DMCMC_STAMPS per-wave log holds */
+__device__ unsigned long long g_wave_log[4 * MCMC_WAVE_LOG];   /* per tile: launch cycles, (XCC_ID << 32) | HW_ID, e-chunks, e-days << 32 | hull days */
 #ifdef MCMC_STAMPS
 struct PhaseClock {
     unsigned long long t[PH_COUNT];
@@ -147,10 +149,23 @@ struct PhaseClock {
         last = now;
     }
     __device__ __forceinline__ void count(int k, int n) { t[k] += (unsigned long long)n; }
-    __device__ __forceinline__ void flush(unsigned lane) {
+    __device__ __forceinline__ void flush(unsigned lane, int tile) {
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < PH_COUNT; ++k) atomicAdd(&g_phase_cycles[k], t[k]);
+            /* slot 15: the slowest wave's cycles over its launch (load imbalance = this / mean) */
+            unsigned long long tot = 0;
+#pragma unroll
+            for (int k = 0; k < PH_COUNT; ++k)
+                if (k != PH_NCHUNK && k != PH_NCHUNK_E && k != PH_EDAYS && k != PH_EHULL) tot += t[k];
+            atomicMax(&g_phase_cycles[15], tot);
+            if (tile < MCMC_WAVE_LOG) {
+                const unsigned long long hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                g_wave_log[4 * tile] = tot;
+                g_wave_log[4 * tile + 1] = (xcc << 32) | hw;
+                g_wave_log[4 * tile + 2] = t[PH_NCHUNK_E];
+                g_wave_log[4 * tile + 3] = (t[PH_EDAYS] << 32) | t[PH_EHULL];
+            }
         }
     }
 };
@@ -159,7 +174,7 @@ struct PhaseClock {
     __device__ __forceinline__ void start() {}
     __device__ __forceinline__ void stamp(int) {}
     __device__ __forceinline__ void count(int, int) {}
-    __device__ __forceinline__ void flush(unsigned) {}
+    __device__ __forceinline__ void flush(unsigned, int) {}
 };
 #endif
 
@@ -839,6 +854,7 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                 if (__builtin_amdgcn_readfirstlane(__any(hasE) ? 1 : 0)) {
                     keLo = min(keLo, i);
                     keHi = max(keHi, i);
+                    pc.count(PH_EDAYS, 1);
                     const double ne = -e;
                     if constexpr (FUSE && T == 8 && MCMC_DPP_ROWS) {
 #pragma unroll
@@ -894,6 +910,7 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
             }
             pc.stamp(PH_DAYS);
         }
+        pc.count(PH_EHULL, keHi >= keLo ? keHi - keLo + 1 : 0);
         /* log-likelihood of this pass (covid.h:488-492), data days in order: the output
          * coord `dead` is the first pass's weighted deaths (multset, covid.h:475), plus this
          * pass's in the second (multadd, covid.h:484).  A streaming loop over two per-lane
@@ -934,7 +951,9 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
 /* days per register block of the fast mode.  Fixed: a T=16 build (fewer history loads per
  * multiply-add) needs 256+256 registers, 399 SGPR spills and scratch for its unrolled day loop
  * and ended in a memory fault on the GPU when tried; only T=8 is validated on hardware. */
+#ifndef MCMC_TF
 #define MCMC_TF 8
+#endif
 #include "mcmc_model_f32.hip.h"
 
 /* t / dx / dx / dx of SmoothnessPrior::eval (mcmc.h:208).  When dx = L/n is a power of two
@@ -1398,7 +1417,7 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
         }
         pc.stamp(PH_ACCEPT);
     }
-    pc.flush(lane);
+    pc.flush(lane, tile);
 
     rng_u[lane] = rnd.state;
     if constexpr (!MULTI) {

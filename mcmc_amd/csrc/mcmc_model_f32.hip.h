@@ -172,6 +172,25 @@ __device__ __forceinline__ void lag_tail_f(float2_t (&acc)[P_N][T], const float 
     }
 }
 
+/* -DMCMC_F32_CHECK (diagnosis builds, e.g. of another MCMC_TF): every row range the evaluation is about to
+ * touch is compared with the size of its buffer first; the first violation is recorded in g_f32_check
+ * (kind, low, high, bound) and the evaluation returns NaN instead of making the access. */
+__device__ int g_f32_check[4];
+#ifdef MCMC_F32_CHECK
+#define F32_ROWS(kind, lo, hi, bound)                                                                    \
+    do {                                                                                                 \
+        if ((lo) < 0 || (hi) >= (bound)) {                                                               \
+            if (lane == 0 && atomicCAS(&g_f32_check[0], 0, (kind)) == 0) {                               \
+                g_f32_check[1] = (lo); g_f32_check[2] = (hi); g_f32_check[3] = (bound);                  \
+            }                                                                                            \
+            return __builtin_nan("");                                                                    \
+        }                                                                                                \
+    } while (0)
+#else
+#define F32_ROWS(kind, lo, hi, bound) do { } while (0)
+#endif
+enum { F32K_HIST_ZERO = 1, F32K_HIST_WINDOW, F32K_DAY_CONST, F32K_HIST_SKIP, F32K_TABLE_FIRST, F32K_TABLE_LAST, F32K_HIST_REFILL, F32K_HIST_DAYS };
+
 /*
  * The fast-mode model evaluation for the chain of this lane; returns loglike (double).
  * B.hn_u / B.he_u are used as float rows (the buffers are sized for doubles), B.d1s_u stays
@@ -190,6 +209,8 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
     const double* xdisc_u = B.x_u + M.nB * MCMC_WAVE;
     constexpr int HOFF = 2 * T;
     const double invPop = 1.0 / M.pop;
+    [[maybe_unused]] const int histF = 2 * (M.size + 4 * MCMC_T + MCMC_HOFF(MCMC_T));   /* float rows of hn / he (set_data's histRows doubles) */
+    [[maybe_unused]] const int rowsF = M.size + 3 * T;                                 /* rows of RF / RFn */
 
     double loglike = 0;
     int start = (int)((double)md - lp.delay);                       /* covid.h:331 */
@@ -206,6 +227,8 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
         int keLo = 0x7fffffff, keHi = -1;
 
         float ncur = (s == ws) ? 1.0f : 0.0f;                       /* patient zero, covid.h:339 */
+        F32_ROWS(F32K_HIST_ZERO, ws - 2 * T + HOFF, ws + HOFF, histF);
+        F32_ROWS(F32K_HIST_WINDOW, ws - T + 1 + HOFF, ws - T + 1 + HOFF + 2 * T - 1, histF);
 #pragma unroll 1
         for (int k = ws - 2 * T; k < ws; ++k) {
             hn_u[(k + HOFF) * MCMC_WAVE + lane] = 0.0f;
@@ -238,16 +261,22 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
             const bool anyE = keHi >= keLo;
             int Lc = j0 - ws + T - 1;
             int c0 = 0;
+            F32_ROWS(F32K_DAY_CONST, j0, j0 + T - 1, M.simPad);
+            F32_ROWS(F32K_HIST_DAYS, j0 + HOFF, j0 + T + HOFF, histF);              /* phase B: rows i and i+1 */
+            F32_ROWS(F32K_HIST_REFILL, ws - T + 1 + HOFF, ws - T + 1 + HOFF + (b + 2) * T - 1, histF);   /* refills of the last chunk */
             if (Lc - T + 1 >= M.nLagRows) {                          /* rows of zeros: skipped (covid.h:378) */
                 c0 = (Lc - T + 1 - M.nLagRows) / T + 1;
                 if (c0 > b) c0 = b;
                 Lc -= c0 * T;
+                F32_ROWS(F32K_HIST_SKIP, ws - T + 1 + HOFF + c0 * T, ws - T + 1 + HOFF + c0 * T + 2 * T - 1, histF);
 #pragma unroll
                 for (int q = 0; q < T; ++q) {
                     WA[q] = hbase[(c0 * T + q) * MCMC_WAVE + lane];
                     WB[q] = hbase[(c0 * T + q + T) * MCMC_WAVE + lane];
                 }
             }
+            F32_ROWS(F32K_TABLE_FIRST, Lc - 1, Lc, rowsF);
+            if (b > c0) F32_ROWS(F32K_TABLE_LAST, Lc - (b - 1 - c0) * T - T - 1, Lc, rowsF);   /* lowest row the last chunk requests */
             float16u_t cur = smem_rows2(RFpos, Lc - 1);
             const float* hnx = hbase + (c0 + 2) * T * MCMC_WAVE;
             int cLo = b, cHi = b - 1;

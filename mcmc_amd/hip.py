@@ -31,7 +31,7 @@ SYMBOLS = [
     "mcmc_hip_get_samples", "mcmc_hip_get_sample_all", "mcmc_hip_get_mean", "mcmc_hip_eval",
     "mcmc_hip_derive", "mcmc_hip_diagnostics", "mcmc_hip_last_timing", "mcmc_hip_pair_count",
     "mcmc_hip_executed_pair_count", "mcmc_hip_eval_static", "mcmc_hip_eval_static_max",
-    "mcmc_hip_debug_phase_cycles", "mcmc_hip_set_ladder", "mcmc_hip_swap", "mcmc_hip_run_tempered",
+    "mcmc_hip_debug_phase_cycles", "mcmc_hip_debug_wave_log", "mcmc_hip_debug_f32_check", "mcmc_hip_set_ladder", "mcmc_hip_swap", "mcmc_hip_run_tempered",
     "mcmc_hip_get_rungs", "mcmc_hip_get_swap_counts", "mcmc_hip_toy_dim", "mcmc_hip_toy_n_out", "mcmc_hip_toy_eval", "mcmc_hip_toy_run",
 ]
 
@@ -111,6 +111,8 @@ def lib():
     L.mcmc_hip_pair_count.argtypes = [vp, dp, C.c_int32]
     L.mcmc_hip_executed_pair_count.argtypes = [vp, dp, C.c_int32]
     L.mcmc_hip_debug_phase_cycles.argtypes = [vp, dp, C.c_int32]
+    L.mcmc_hip_debug_wave_log.argtypes = [vp, dp, C.POINTER(C.c_uint64), dp, dp, dp, C.c_int64]
+    L.mcmc_hip_debug_f32_check.argtypes = [vp, C.POINTER(C.c_int32)]
     L.mcmc_hip_set_ladder.argtypes = [vp, C.c_int32, dp, C.c_uint64, C.c_uint64]
     L.mcmc_hip_swap.argtypes = [vp, C.c_int32]
     L.mcmc_hip_run_tempered.argtypes = [vp, C.c_int32, C.c_int32]
@@ -386,12 +388,26 @@ class CovidSampler:
         _check(lib().mcmc_hip_last_timing(self._h, C.byref(a), C.byref(s), C.byref(k), C.byref(n)))
         return dict(adjust_s=a.value, sampling_s=s.value, step_kernel_s=k.value, launches=n.value)
 
-    PHASES = ["propose", "setup", "chunks", "tail", "days", "loglike", "prior", "accept", "record", "chunks_e", "n_chunks", "n_chunks_e", "wait"]
+    PHASES = ["propose", "setup", "chunks", "tail", "days", "loglike", "prior", "accept", "record", "chunks_e", "n_chunks", "n_chunks_e", "wait", "e_days", "e_hull"]
 
     def phase_cycles(self, reset=False):
         out = np.zeros(16)
         _check(lib().mcmc_hip_debug_phase_cycles(self._h, _dp(out), int(reset)))
-        return dict(zip(self.PHASES, out[:len(self.PHASES)]))
+        d = dict(zip(self.PHASES, out[:len(self.PHASES)]))
+        d["slowest_wave"] = out[15]        # max over waves of one launch's cycles
+        return d
+
+    def f32_check(self):
+        out = (C.c_int32 * 4)()
+        _check(lib().mcmc_hip_debug_f32_check(self._h, out))
+        return list(out)
+
+    def wave_log(self, n_tiles):
+        cyc, hw = np.zeros(n_tiles), np.zeros(n_tiles, dtype=np.uint64)
+        ech, eda, ehu = np.zeros(n_tiles), np.zeros(n_tiles), np.zeros(n_tiles)
+        _check(lib().mcmc_hip_debug_wave_log(self._h, _dp(cyc), hw.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                             _dp(ech), _dp(eda), _dp(ehu), n_tiles))
+        return cyc, hw, ech, eda, ehu
 
     def pair_count(self, reset=False):
         v = C.c_double()

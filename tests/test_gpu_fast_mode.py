@@ -156,3 +156,16 @@ def test_fast_mode_needs_fma_contraction_and_a_known_mode(R11, R10):
     with pytest.raises(RuntimeError, match="unknown mode"):
         H._check(H.lib().mcmc_hip_set_precision(s._h, 7))
     s.close()
+
+
+def test_zz_row_checks_of_a_diagnosis_build_are_clean(R11, R10):
+    """Libraries built with -DMCMC_F32_CHECK (tools/build_variants.sh, e.g. for another MCMC_TF) compare
+    every row range of the fast-mode evaluation with its buffer before touching it and record the first
+    violation; the tests above have run in this process, so the record covers them.  The product build
+    compiles the checks out and always reports zeros."""
+    cfg = make_cfg(60, R11, contract=1, **SMALL)
+    s = H.CovidSampler(cfg, R10, precision="f32_model")
+    s.eval(perturbed(cfg, 70, 0.1))
+    kind, lo, hi, bound = s.f32_check()
+    s.close()
+    assert kind == 0, f"row range kind {kind}: rows [{lo}, {hi}] outside a buffer of {bound} rows"

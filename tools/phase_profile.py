@@ -19,11 +19,13 @@ s.step(steps, 1.0, True)
 dt = time.perf_counter() - t0
 ph = s.phase_cycles()
 print(f"{n * steps / dt / 1e6:.2f} M steps/s (stamped build), acceptance {s.accept_counts().mean():.1f} per chain since reset")
-counts = {k: ph.pop(k) for k in ("n_chunks", "n_chunks_e")}
+counts = {k: ph.pop(k) for k in ("n_chunks", "n_chunks_e", "e_days", "e_hull")}
+slowest = ph.pop("slowest_wave")
 tot = sum(ph.values())
 waves = (n + 63) // 64
 for k, v in ph.items():
     print(f"{k:8s} {v / waves / steps:12.0f} cycles/wave/step  {100 * v / max(tot, 1):5.1f} %")
 print(f"total    {tot / waves / steps:12.0f} cycles/wave/step")
+print(f"slowest wave of a launch {slowest / steps:12.0f} cycles/step = {slowest / steps / (tot / waves / steps):.3f} x the mean (launches of {steps} steps)")
 for k, v in counts.items():
     print(f"{k:10s} {v / waves / steps:10.1f} per wave per step")
