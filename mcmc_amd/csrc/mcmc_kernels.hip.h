@@ -948,12 +948,15 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
     return loglike;
 }
 
-/* days per register block of the fast mode.  Fixed: a T=16 build (fewer history loads per
- * multiply-add) needs 256+256 registers, 399 SGPR spills and scratch for its unrolled day loop
- * and ended in a memory fault on the GPU when tried; only T=8 is validated on hardware. */
+/* days per register block of the fast mode.  8 on performance grounds: a -DMCMC_TF=16 build (fewer history
+ * loads per multiply-add) is memory-safe -- a -DMCMC_F32_CHECK build of it ran the fast-mode tests on an
+ * MI355X with every row range compared against its buffer, no violation, and the plain build ran them clean
+ * (profiles/r02/f_fast_mode_tf16_checked_run.txt) -- but its unrolled 16-day sequential part spills 473 SGPRs
+ * and 68 VGPRs to scratch and it is 14 % slower (23.2 against 27.1 M steps/s). */
 #ifndef MCMC_TF
 #define MCMC_TF 8
 #endif
+static_assert(MCMC_TF == 8 || MCMC_TF == 16, "fast-mode block sizes validated on hardware: 8 (product) and 16");
 #include "mcmc_model_f32.hip.h"
 
 /* t / dx / dx / dx of SmoothnessPrior::eval (mcmc.h:208).  When dx = L/n is a power of two
