@@ -219,7 +219,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-leg", action="store_true", help="skip the FP32 fast-mode leg (N=1 only)")
     ap.add_argument("--no-strict-leg", action="store_true", help="skip the strict (no FMA contraction) leg (N=1 only)")
-    ap.add_argument("--precision", default="f64", choices=["f64", "f32_model"],
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32_model", "f32_packed"],
                     help="arithmetic of the MAIN leg; f32_model (fast mode) is for profiling that kernel only: "
                          "the line then says dtype f32+f64 and is not the headline metric")
     ap.add_argument("--ess-chains", type=int, default=4096, help="chains of the ESS leg (0: skip it)")

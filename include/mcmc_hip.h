@@ -136,13 +136,14 @@ int mcmc_hip_get_region_stepsizes(mcmc_hip_ctx* ctx, double* out /*[n_chains][n_
  * arithmetic is `using Float = double` (mcmc.h:43) = MCMC_HIP_PRECISION_F64, the default and
  * the only mode held to bit-exact parity.  MCMC_HIP_PRECISION_F32_MODEL ("fast mode", the FP32
  * figure north_star asks for) runs the renewal convolution of DiseaseSpread::eval
- * (covid.h:376-410,426-428) in packed single precision and everything else -- proposal,
+ * (covid.h:376-410,426-428) in single precision and everything else -- proposal,
  * capacity test, feedback, likelihood sum, prior, accept -- in double; it needs
  * cfg.contract = 1 and is held to a statistical bar (tests/test_gpu_fast_mode.py).
  * Call after set_tables and before set_chains; eval/derive: eval follows the mode, derive is
  * always double. */
 #define MCMC_HIP_PRECISION_F64        0
-#define MCMC_HIP_PRECISION_F32_MODEL  1
+#define MCMC_HIP_PRECISION_F32_MODEL  1   /* the fast mode: convolution on the FP32 matrix cores (v_mfma_f32_32x32x2_f32) */
+#define MCMC_HIP_PRECISION_F32_PACKED 2   /* its first form, packed FP32 vector multiply-adds; kept for comparison */
 int mcmc_hip_set_precision(mcmc_hip_ctx* ctx, int32_t mode);
 
 /* Replaces ChainManager's per-chain setup loop (mcmc.h:1517-1532): n chains, chain i has

@@ -283,7 +283,9 @@ constexpr size_t kLdsSolo = 81 * 1024;
 template <typename K, typename... Args>
 int launch_chain_kernel(mcmc_hip_ctx* c, K kernel, bool derive, int T, Args... args) {
     const unsigned grid = (unsigned)((c->nTiles + MCMC_WAVES_PER_BLOCK - 1) / MCMC_WAVES_PER_BLOCK);
-    size_t shmem = lds_bytes(c->M, derive, T);
+    /* the fast mode on the matrix cores has an LDS image of its own (float tables + transposition buffers) */
+    const bool f32Image = !derive && !c->multi && c->precision == MCMC_HIP_PRECISION_F32_MODEL;
+    size_t shmem = f32Image ? lds_bytes_f32(c->M) : lds_bytes(c->M, derive, T);
     if (c->multi && !derive)           /* + one region slice per wave (stage_region) */
         shmem = ((shmem + 7) / 8 + (size_t)MCMC_WAVES_PER_BLOCK * region_slice_doubles(c->M)) * sizeof(double);
     if (shmem > kLdsMax)
@@ -301,6 +303,8 @@ int run_eval_current(mcmc_hip_ctx* c) {
         return launch_chain_kernel(c, eval_kernel<MCMC_T, false, 0, true>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
     }
     if (c->precision == MCMC_HIP_PRECISION_F32_MODEL)
+        return launch_chain_kernel(c, eval_kernel<MCMC_T, true, 2>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
+    if (c->precision == MCMC_HIP_PRECISION_F32_PACKED)
         return launch_chain_kernel(c, eval_kernel<MCMC_T, true, 1>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
     if (c->cfg.contract) return launch_chain_kernel(c, eval_kernel<MCMC_T, true>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
     return launch_chain_kernel(c, eval_kernel<MCMC_T, false>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
@@ -314,6 +318,8 @@ int launch_steps(mcmc_hip_ctx* c, int nSteps, const double* dBetas, const int* d
         return launch_chain_kernel(c, mh_step_kernel<MCMC_T, false, 0, true>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0, hc);
     }
     if (c->precision == MCMC_HIP_PRECISION_F32_MODEL)
+        return launch_chain_kernel(c, mh_step_kernel<MCMC_T, true, 2>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0, hc);
+    if (c->precision == MCMC_HIP_PRECISION_F32_PACKED)
         return launch_chain_kernel(c, mh_step_kernel<MCMC_T, true, 1>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0, hc);
     if (c->cfg.contract)
         return launch_chain_kernel(c, mh_step_kernel<MCMC_T, true>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0, hc);
@@ -630,9 +636,9 @@ int mcmc_hip_set_regions(mcmc_hip_ctx* c, int32_t n_regions, const int32_t* pop_
 
 int mcmc_hip_set_precision(mcmc_hip_ctx* c, int32_t mode) try {
     if (int r = check_ctx(c)) return r;
-    if (mode != MCMC_HIP_PRECISION_F64 && mode != MCMC_HIP_PRECISION_F32_MODEL)
+    if (mode != MCMC_HIP_PRECISION_F64 && mode != MCMC_HIP_PRECISION_F32_MODEL && mode != MCMC_HIP_PRECISION_F32_PACKED)
         return fail(MCMC_HIP_EINVAL, "set_precision: unknown mode %d", mode);
-    if (mode == MCMC_HIP_PRECISION_F32_MODEL) {
+    if (mode != MCMC_HIP_PRECISION_F64) {
         if (!c->haveTables) return fail(MCMC_HIP_ESTATE, "set_precision: call set_tables first");
         if (!c->cfg.contract) return fail(MCMC_HIP_EINVAL, "set_precision: the fast mode needs cfg.contract = 1");
         if (c->multi) return fail(MCMC_HIP_EINVAL, "set_precision: the multi-region model runs in double only");
@@ -1039,7 +1045,7 @@ static int with_external(mcmc_hip_ctx* c, int64_t n, const double* params, bool 
     const int R = c->nRegions;
     /* a temporary lane set so that chain state is untouched */
     mcmc_hip_ctx tmp;
-    tmp.multi = c->multi && !derive; tmp.nRegions = R; tmp.dimRegion = c->dimRegion;
+    tmp.multi = c->multi && !derive; tmp.nRegions = R; tmp.dimRegion = c->dimRegion; tmp.precision = c->precision;
     tmp.cfg = c->cfg; tmp.device = c->device; tmp.nCU = c->nCU; tmp.stream = c->stream; tmp.size = c->size;
     tmp.simPad = c->simPad; tmp.histRows = c->histRows; tmp.dim = dim; tmp.nP = nP; tmp.nChains = n;
     tmp.M = c->M; tmp.nTiles = (int)(nP / MCMC_WAVE);
@@ -1064,7 +1070,8 @@ static int with_external(mcmc_hip_ctx* c, int64_t n, const double* params, bool 
             if (c->cfg.contract) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true, 0, true>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
             else rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, false, 0, true>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
         } else {
-            if (c->precision == MCMC_HIP_PRECISION_F32_MODEL) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true, 1>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
+            if (c->precision == MCMC_HIP_PRECISION_F32_MODEL) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true, 2>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
+            else if (c->precision == MCMC_HIP_PRECISION_F32_PACKED) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true, 1>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
             else if (c->cfg.contract) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
             else rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, false>, false, MCMC_T, tmp.M, tmp.S, (const double*)soa.p, res.p);
         }
@@ -1137,6 +1144,7 @@ int mcmc_hip_eval_static(mcmc_hip_ctx* c, int64_t n, const double* params_dev, d
     S.dim = dim; S.nChains = n;
     mcmc_hip_ctx tmp;                      /* launch geometry only: borrows the stream, owns nothing */
     tmp.cfg = c->cfg; tmp.device = c->device; tmp.nCU = c->nCU; tmp.stream = c->stream; tmp.M = c->M;
+    tmp.precision = c->precision;
     tmp.nTiles = S.nTiles; tmp.nP = nP; tmp.nChains = n; tmp.dim = dim;
     const unsigned tb = 256, tg = (unsigned)((nP + tb - 1) / tb);
     hipLaunchKernelGGL(tile_in_kernel<double>, dim3(tg), dim3(tb), 0, c->stream, params_dev, soa, (long long)n, dim, nP);
@@ -1144,7 +1152,8 @@ int mcmc_hip_eval_static(mcmc_hip_ctx* c, int64_t n, const double* params_dev, d
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) rc = fail(MCMC_HIP_EHIP, "tile_in launch failed: %s", hipGetErrorString(e));
     if (!rc) {
-        if (c->precision == MCMC_HIP_PRECISION_F32_MODEL) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true, 1>, false, MCMC_T, tmp.M, S, (const double*)soa, res);
+        if (c->precision == MCMC_HIP_PRECISION_F32_MODEL) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true, 2>, false, MCMC_T, tmp.M, S, (const double*)soa, res);
+        else if (c->precision == MCMC_HIP_PRECISION_F32_PACKED) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true, 1>, false, MCMC_T, tmp.M, S, (const double*)soa, res);
         else if (c->cfg.contract) rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, true>, false, MCMC_T, tmp.M, S, (const double*)soa, res);
         else rc = launch_chain_kernel(&tmp, eval_kernel<MCMC_T, false>, false, MCMC_T, tmp.M, S, (const double*)soa, res);
     }

@@ -210,6 +210,10 @@ struct LdsView {
     const double* deaths;     /* [nData]  */
     const double* sigma2;     /* [nData]  */
     const int* seg;           /* [simPad] */
+    /* fast mode on the matrix cores only (stage_lds_f32, mcmc_model_f32.hip.h); null otherwise */
+    const float* tabF;        /* [F32_TAB_PAD + rowsL][8] float response table, F32_TAB_PAD rows of zeros in front */
+    const float* tabN;        /* same shape: the capacity-correction columns (0 0 0 0 -SFS -RFS 1-DFS 0) */
+    float* tr;                /* [waves of the workgroup][64][65] transposition buffers */
 };
 
 __host__ __device__ inline int lds_rows(const DevModel& M, bool derive, int T) {
@@ -246,7 +250,59 @@ __device__ inline LdsView stage_lds(const DevModel& M, double* lds, bool derive,
     __syncthreads();
     LdsView v;
     v.Rpos = rp; v.Rneg = rn; v.capacity = cap; v.deaths = dea; v.sigma2 = sg2; v.seg = seg;
+    v.tabF = nullptr; v.tabN = nullptr; v.tr = nullptr;
     return v;
+}
+
+/* LDS image of the fast mode on the matrix cores: no double tables (its sequential part takes rows 0..7
+ * through the scalar cache), the per-day constants as above, the two float tables the MFMA B operands are
+ * read from, and one 64 x 65 float transposition buffer per wave.  Lags reach horizon + 7 (day j0 + 7 of the
+ * last block against the wave's first day); sources all of whose lags are >= nLagRows are skipped in blocks
+ * of 8 days, so no row above nLagRows + 13 is read either. */
+#define F32_TAB_PAD 2         /* the B operand of the pair after the last one is requested too: rows 0 and -1 */
+#define F32_TR_FLOATS (MCMC_WAVE * 65)
+__host__ __device__ inline int lds_rows_f32(const DevModel& M) {
+    const int a = M.simDays + 8, b = M.nLagRows + 16;
+    return a < b ? a : b;
+}
+__host__ __device__ inline size_t lds_bytes_f32(const DevModel& M) {
+    return sizeof(double) * ((size_t)M.simPad + 2 * (size_t)M.nData) + sizeof(int) * (size_t)(M.simPad + (M.simPad & 1)) +
+           sizeof(float) * ((size_t)2 * (F32_TAB_PAD + lds_rows_f32(M)) * 8 + (size_t)MCMC_WAVES_PER_BLOCK * F32_TR_FLOATS) + 16;
+}
+__device__ inline LdsView stage_lds_f32(const DevModel& M, double* lds) {
+    const int rows = lds_rows_f32(M);
+    double* cap = lds;
+    double* dea = cap + M.simPad;
+    double* sg2 = dea + M.nData;
+    int* seg = (int*)(sg2 + M.nData);
+    float* tf = (float*)(seg + M.simPad + (M.simPad & 1));
+    float* tn = tf + (size_t)(F32_TAB_PAD + rows) * 8;
+    float* tr = tn + (size_t)(F32_TAB_PAD + rows) * 8;
+    for (int i = threadIdx.x; i < M.simPad; i += blockDim.x) {
+        cap[i] = M.capacity[i];
+        seg[i] = M.seg[i];
+    }
+    for (int i = threadIdx.x; i < M.nData; i += blockDim.x) {
+        dea[i] = M.deaths[i];
+        sg2[i] = M.sigma2[i];
+    }
+    for (int i = threadIdx.x; i < (F32_TAB_PAD + rows) * 8; i += blockDim.x) {
+        const int r = i / 8 - F32_TAB_PAD, c = i % 8;
+        tf[i] = r >= 0 ? M.RF[r * 8 + c] : 0.0f;
+        tn[i] = (r >= 0 && c >= 4 && c < 7) ? M.RFn[r * 4 + (c - 4)] : 0.0f;
+    }
+    __syncthreads();
+    LdsView v;
+    v.Rpos = nullptr; v.Rneg = nullptr; v.capacity = cap; v.deaths = dea; v.sigma2 = sg2; v.seg = seg;
+    v.tabF = tf; v.tabN = tn; v.tr = tr;
+    return v;
+}
+/* PREC: 0 = double (the reference's arithmetic), 1 = fast mode with packed FP32 multiply-adds, 2 = fast mode
+ * with the convolution on the matrix cores */
+template <int PREC>
+__device__ inline LdsView stage_lds_for(const DevModel& M, double* lds, int T) {
+    if constexpr (PREC == 2) return stage_lds_f32(M, lds);
+    else return stage_lds(M, lds, false, T);
 }
 
 /*
@@ -1220,7 +1276,7 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
                                                  const int* __restrict__ flags, int slot0, long long headCounter) {
     static_assert(!(MULTI && PREC != 0), "the multi-region model runs in double only");
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
-    const LdsView lds = stage_lds(M, lds_raw, false, T);
+    const LdsView lds = stage_lds_for<PREC>(M, lds_raw, T);
     const unsigned lane = threadIdx.x & (MCMC_WAVE - 1);
     const int tile = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * MCMC_WAVES_PER_BLOCK + threadIdx.x / MCMC_WAVE));
     if (tile >= S.nTiles) return;
@@ -1314,7 +1370,7 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
             const bool behChanged = propose(M, rnd, xc_u, xp_u, lane, stepsize, lp, llpNew);
             pc.stamp(PH_PROPOSE);
             double llm;
-            if constexpr (PREC == 1) llm = eval_model_f32<MCMC_TF>(M, lds, B, lp, lane, work, pc);   /* fast mode */
+            if constexpr (PREC != 0) llm = eval_model_f32<MCMC_TF, PREC == 2>(M, lds, B, lp, lane, work, pc);   /* fast mode */
             else llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, work, pc);
             double llp = 0.0;
             double delta = 0;                                           /* mcmc.h:604-606 */
@@ -1438,7 +1494,7 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
 template <int T, bool FUSE, int PREC = 0, bool MULTI = false>
 __global__ MCMC_KERNEL_ATTRS void eval_kernel(DevModel M, ChainState S, const double* x, double* llOut) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
-    const LdsView lds = stage_lds(M, lds_raw, false, T);
+    const LdsView lds = stage_lds_for<PREC>(M, lds_raw, T);
     const unsigned lane = threadIdx.x & (MCMC_WAVE - 1);
     const int tile = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * MCMC_WAVES_PER_BLOCK + threadIdx.x / MCMC_WAVE));
     if (tile >= S.nTiles) return;
@@ -1467,7 +1523,7 @@ __global__ MCMC_KERNEL_ATTRS void eval_kernel(DevModel M, ChainState S, const do
         LaneScalars lp;
         load_lane_scalars(M, B.x_u, lane, lp);
         double llm;
-        if constexpr (PREC == 1) llm = eval_model_f32<MCMC_TF>(M, lds, B, lp, lane, work, pc);
+        if constexpr (PREC != 0) llm = eval_model_f32<MCMC_TF, PREC == 2>(M, lds, B, lp, lane, work, pc);
         else llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, work, pc);
         const double llp = M.hasPrior ? eval_prior(M, B.x_u, lane) : 0.0;
         llOut[((size_t)tile * 2) * MCMC_WAVE + lane] = llm;

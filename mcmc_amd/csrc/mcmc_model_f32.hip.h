@@ -23,6 +23,19 @@
  *    dead -= e*DFS become one operation;
  *  - no cross-lane row tricks: rows 0..T-1 of the sequential part come from the scalar cache
  *    as well.
+ *
+ * MFMA = true (the default fast mode, MCMC_HIP_PRECISION_F32_MODEL) moves the whole contraction over the source
+ * days BEFORE a block onto the FP32 matrix cores: for a tile of 64 chains and the block's 8 days,
+ *     C[chain][(t, c)] = sum_k hist[k][chain] * table[j0 + t - k][c]
+ * is a (64 x K) x (K x 64) product whose B operand is Toeplitz in (k, t).  v_mfma_f32_32x32x2_f32 takes
+ * M = 32 chains, N = 32 = 4 days x 8 curves and K = 2 source days: lane l supplies A = hist[k0 + l/32][l%32]
+ * (one coalesced dword of the float history) and B = table[(j0 - k0 - l/32) * 8 + l%32], 32 consecutive floats
+ * of the LDS image because (day, curve) -> 8 * day + curve.  Four MFMAs (2 chain halves x 2 day halves) do the
+ * 8 192 multiply-adds of two source days; the capacity corrections are the same product with the e-history as
+ * A and the table (0 0 0 0 -SFS -RFS 1-DFS 0) as B over the source days that carry any.  At the end of the
+ * block the 64 sums of a chain go from the MFMA layout to chain-per-lane through an LDS buffer of the wave's
+ * own (rows of 65 floats), and the sequential part runs as before.  Summation order differs from the packed
+ * form (pairs of source days, then the in-block sources); both are FP32 and held to the same statistical bar.
  */
 #pragma once
 
@@ -172,6 +185,107 @@ __device__ __forceinline__ void lag_tail_f(float2_t (&acc)[P_N][T], const float 
     }
 }
 
+
+/* ------------------------------------------------------------ phase A on the matrix cores ---- */
+typedef float float16v_t __attribute__((ext_vector_type(16)));
+
+/* Streams nPairs pairs of source days (a multiple of GRAN) through the four accumulator tiles.  hp: the
+ * lane's A pointer of pair 0 (row k0 + lane/32, chain lane%32 of the float history; +32 = the other chain
+ * half; a pair on = +128 floats); li: the lane's LDS index of pair 0's B value for days j0..j0+3 (+32: days
+ * j0+4..j0+7; a pair on = -16).  RING pairs of A values are in flight; the B values of the NEXT pair are
+ * requested ahead of the current pair's MFMAs, which block the wave's issue for 64 cycles each.  Reads ahead
+ * of the last pair stay inside the history buffer (rows < j0 + 2 RING + 2) and the table's pad rows. */
+template <int RING, int GRAN>
+__device__ __forceinline__ void mfma_stream(float16v_t (&C)[2][2], const float* hp, const float* tab, int li, int nPairs) {
+    float ra[RING][2];
+#pragma unroll
+    for (int u = 0; u < RING; ++u) {
+        ra[u][0] = hp[u * 128];
+        ra[u][1] = hp[u * 128 + 32];
+    }
+    float b0 = tab[li], b1 = tab[li + 32];
+    const float* hq = hp + RING * 128;
+    int rem = nPairs;
+    while (rem > 0) {
+#pragma unroll
+        for (int u = 0; u < RING; ++u) {
+            if (u % GRAN == 0 && u > 0) {
+                if (rem <= 0) break;
+            }
+            li -= 16;
+            const float nb0 = tab[li];
+            const float nb1 = tab[li + 32];
+            __builtin_amdgcn_sched_barrier(0);
+            const float a0 = ra[u][0], a1 = ra[u][1];
+            C[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, C[0][0], 0, 0, 0);
+            C[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, C[0][1], 0, 0, 0);
+            C[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, C[1][0], 0, 0, 0);
+            C[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, C[1][1], 0, 0, 0);
+            ra[u][0] = hq[u * 128];
+            ra[u][1] = hq[u * 128 + 32];
+            b0 = nb0;
+            b1 = nb1;
+            __builtin_amdgcn_sched_barrier(0);
+            if (u % GRAN == GRAN - 1) rem -= GRAN;
+        }
+        hq += RING * 128;
+    }
+}
+
+/* All sources before the block (days kLo .. j0-1, kLo = ws + a multiple of 8) for the block's 8 days, the
+ * capacity corrections of the source days [eLo, eHi] among them, and the hand-over to chain-per-lane. */
+template <int T>
+__device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsView& lds, float* tr, const float* hn_u,
+                                             const float* he_u, int ws, int j0, int kLo, int eLo, int eHi,
+                                             unsigned lane, PhaseClock& pc) {
+    static_assert(T == 8, "one block = 2 x 32 MFMA columns = 8 days x 8 curves");
+    constexpr int HOFF = 2 * T;
+    const int half = (int)(lane >> 5), n = (int)(lane & 31);
+    float16v_t C[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) C[a][b][i] = 0.0f;
+    {
+        const float* hp = hn_u + (kLo + half + HOFF) * MCMC_WAVE + n;
+        const int li = (j0 - kLo - half + F32_TAB_PAD) * 8 + n;
+        mfma_stream<16, 4>(C, hp, lds.tabF, li, (j0 - kLo) / 2);
+    }
+    pc.stamp(PH_CHUNKS);
+    if (eHi >= eLo) {
+        /* pairs are aligned to ws; those touching [eLo, eHi], not before kLo, not into the block */
+        int pLo = (max(eLo, kLo) - ws) / 2, pHi = min((eHi - ws) / 2, (j0 - ws) / 2 - 1);
+        if (pHi >= pLo) {
+            const int k0 = ws + 2 * pLo;
+            const float* hp = he_u + (k0 + half + HOFF) * MCMC_WAVE + n;
+            const int li = (j0 - k0 - half + F32_TAB_PAD) * 8 + n;
+            mfma_stream<4, 1>(C, hp, lds.tabN, li, pHi - pLo + 1);
+        }
+    }
+    pc.stamp(PH_CHUNKS_E);
+    /* MFMA layout -> chain per lane: element v of tile (mt, nt) is chain 32 mt + 8 (v/4) + 4 half + v%4,
+     * column 32 nt + n (= day 4 nt + n/8, curve n%8) */
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                tr[(32 * mt + 8 * (v / 4) + 4 * half + (v % 4)) * 65 + 32 * nt + n] = C[mt][nt][v];
+    __builtin_amdgcn_s_waitcnt(0xc07f);                 /* lgkmcnt(0): the wave's own LDS writes have landed */
+    __builtin_amdgcn_wave_barrier();
+    const float* mine = tr + lane * 65;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int c = 0; c < P_N; ++c) acc[c][t] = float2_t{mine[t * 8 + 2 * c], mine[t * 8 + 2 * c + 1]};
+    __builtin_amdgcn_s_waitcnt(0xc07f);                 /* read back before the next block overwrites the buffer */
+    __builtin_amdgcn_wave_barrier();
+    pc.stamp(PH_TAIL);
+}
+
 /* -DMCMC_F32_CHECK (diagnosis builds, e.g. of another MCMC_TF): every row range the evaluation is about to
  * touch is compared with the size of its buffer first; the first violation is recorded in g_f32_check
  * (kind, low, high, bound) and the evaluation returns NaN instead of making the access. */
@@ -196,7 +310,7 @@ enum { F32K_HIST_ZERO = 1, F32K_HIST_WINDOW, F32K_DAY_CONST, F32K_HIST_SKIP, F32
  * B.hn_u / B.he_u are used as float rows (the buffers are sized for doubles), B.d1s_u stays
  * double.  M.RF / M.RFn are the float tables.
  */
-template <int T>
+template <int T, bool MFMA = false>
 __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsView& lds, const WaveBases& B,
                                                  const LaneScalars& lp, unsigned lane, WorkCount& work,
                                                  PhaseClock& pc) {
@@ -224,6 +338,11 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
         const int s = min(start + shift, horizon);
         int ws = wave_min_i32(s);
         ws = min(ws, md);
+        /* On the matrix cores a chain's sums must not depend on who shares its wave: an MFMA adds the two
+         * products of a source-day pair in one step (not as two chained multiply-adds), so pairs and 8-day
+         * blocks are aligned to ABSOLUTE days, not to the wave's first day.  The up to 7 days before ws are
+         * "not started" days for every lane (zeros, handled below like any day i < s). */
+        if constexpr (MFMA) ws &= ~(T - 1);
         int keLo = 0x7fffffff, keHi = -1;
 
         float ncur = (s == ws) ? 1.0f : 0.0f;                       /* patient zero, covid.h:339 */
@@ -240,10 +359,12 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
         const float* hbase = hn_u + (a0 + HOFF) * MCMC_WAVE;
         const float* ebase = he_u + (a0 + HOFF) * MCMC_WAVE;
         float WA[T], WB[T];
+        if constexpr (!MFMA) {
 #pragma unroll
-        for (int q = 0; q < T; ++q) {
-            WA[q] = hbase[q * MCMC_WAVE + lane];
-            WB[q] = hbase[(q + T) * MCMC_WAVE + lane];
+            for (int q = 0; q < T; ++q) {
+                WA[q] = hbase[q * MCMC_WAVE + lane];
+                WB[q] = hbase[(q + T) * MCMC_WAVE + lane];
+            }
         }
         pc.stamp(PH_SETUP);
         double* ds_u = B.d1s_u + (shift == 1 ? 0 : M.nData * MCMC_WAVE);
@@ -256,113 +377,131 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
 #pragma unroll
                 for (int t = 0; t < T; ++t) acc[c][t] = float2_t{0.0f, 0.0f};
 
-            /* ------------- phase A */
             const int b = (j0 - ws) / T;
-            const bool anyE = keHi >= keLo;
-            int Lc = j0 - ws + T - 1;
-            int c0 = 0;
-            F32_ROWS(F32K_DAY_CONST, j0, j0 + T - 1, M.simPad);
-            F32_ROWS(F32K_HIST_DAYS, j0 + HOFF, j0 + T + HOFF, histF);              /* phase B: rows i and i+1 */
-            F32_ROWS(F32K_HIST_REFILL, ws - T + 1 + HOFF, ws - T + 1 + HOFF + (b + 2) * T - 1, histF);   /* refills of the last chunk */
-            if (Lc - T + 1 >= M.nLagRows) {                          /* rows of zeros: skipped (covid.h:378) */
-                c0 = (Lc - T + 1 - M.nLagRows) / T + 1;
-                if (c0 > b) c0 = b;
-                Lc -= c0 * T;
-                F32_ROWS(F32K_HIST_SKIP, ws - T + 1 + HOFF + c0 * T, ws - T + 1 + HOFF + c0 * T + 2 * T - 1, histF);
+            /* what phase B needs from memory: requested while phase A still has work to cover the latency */
+            double beh[T], pcfv[T], capv[T];
+            auto request_block_inputs = [&]() {
 #pragma unroll
-                for (int q = 0; q < T; ++q) {
-                    WA[q] = hbase[(c0 * T + q) * MCMC_WAVE + lane];
-                    WB[q] = hbase[(c0 * T + q + T) * MCMC_WAVE + lane];
+                for (int t = 0; t < T; ++t) {
+                    const int bi = min(max(j0 + t - md, 0), M.nB - 1);
+                    beh[t] = B.x_u[bi * MCMC_WAVE + lane];
+                    const int sg = __builtin_amdgcn_readfirstlane(lds.seg[j0 + t]);
+                    const double dv = xdisc_u[max(sg, 0) * MCMC_WAVE + lane];
+                    pcfv[t] = sg >= 0 ? dv : 1.0;                        /* covid.h:432-444 */
+                    capv[t] = lds.capacity[j0 + t];
                 }
-            }
-            F32_ROWS(F32K_TABLE_FIRST, Lc - 1, Lc, rowsF);
-            if (b > c0) F32_ROWS(F32K_TABLE_LAST, Lc - (b - 1 - c0) * T - T - 1, Lc, rowsF);   /* lowest row the last chunk requests */
-            float16u_t cur = smem_rows2(RFpos, Lc - 1);
-            const float* hnx = hbase + (c0 + 2) * T * MCMC_WAVE;
-            int cLo = b, cHi = b - 1;
-            if (anyE) {
-                const int num = keLo - a0 - 2 * T + 2;
-                cLo = num <= 0 ? 0 : (num + T - 1) / T;
-                cHi = (keHi - a0) / T;
-                cLo = max(cLo, c0);
-                cHi = min(cHi, b - 1);
-                if (cHi < cLo) { cLo = b; cHi = b - 1; }
-            }
-            const float* ek0 = ebase + cLo * T * MCMC_WAVE;
-#pragma unroll 1
-            for (int seg = 0; seg < 3; ++seg) {
-                int nch = (seg == 0) ? cLo - c0 : (seg == 1) ? cHi - cLo + 1 : b - 1 - cHi;
-                pc.count(seg == 1 ? PH_NCHUNK_E : PH_NCHUNK, nch);
-                unsigned laneL = lane;
-                asm volatile("" : "+v"(laneL));                      /* see eval_model: nothing pending at the loop header */
-                if (seg != 1) {
-#pragma unroll 1
-                    for (; nch >= 2; nch -= 2) {
-                        lag_chunk_f<T>(acc, WA, WB, cur, RFpos, Lc, hnx, laneL);
-                        lag_chunk_f<T>(acc, WB, WA, cur, RFpos, Lc - T, hnx + T * MCMC_WAVE, laneL);
-                        hnx += 2 * T * MCMC_WAVE;
-                        Lc -= 2 * T;
-                    }
-                    if (nch > 0) {
-                        lag_chunk_f<T>(acc, WA, WB, cur, RFpos, Lc, hnx, laneL);
-#pragma unroll
-                        for (int q = 0; q < T; ++q) { const float tmp = WA[q]; WA[q] = WB[q]; WB[q] = tmp; }
-                        hnx += T * MCMC_WAVE;
-                        Lc -= T;
-                    }
-                } else if (nch > 0) {
-                    float EA[T], EB[T];
+            };
+            if constexpr (MFMA) {
+                /* ------------- phase A on the matrix cores: every source day before the block */
+                int kLo = ws;                                        /* sources whose lags are all >= nLagRows: skipped */
+                if (j0 - M.nLagRows + 1 - ws > 0) kLo += (j0 - M.nLagRows + 1 - ws) / 8 * 8;
+                F32_ROWS(F32K_DAY_CONST, j0, j0 + T - 1, M.simPad);
+                F32_ROWS(F32K_HIST_DAYS, j0 + HOFF, j0 + T + HOFF, histF);
+                F32_ROWS(F32K_HIST_REFILL, kLo + HOFF, j0 + 2 * 16 + 1 + HOFF, histF);   /* the A ring reads 16 pairs ahead */
+                F32_ROWS(F32K_TABLE_FIRST, 0, j0 - kLo + T - 1, lds_rows_f32(M));
+                request_block_inputs();
+                if (j0 > kLo) {
+                    const int waveInBlock = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / MCMC_WAVE));
+                    mfma_sources<T>(acc, lds, lds.tr + waveInBlock * F32_TR_FLOATS, hn_u, he_u, ws, j0, kLo, keLo, keHi, lane, pc);
+                }
+            } else {
+                /* ------------- phase A */
+                const bool anyE = keHi >= keLo;
+                int Lc = j0 - ws + T - 1;
+                int c0 = 0;
+                F32_ROWS(F32K_DAY_CONST, j0, j0 + T - 1, M.simPad);
+                F32_ROWS(F32K_HIST_DAYS, j0 + HOFF, j0 + T + HOFF, histF);              /* phase B: rows i and i+1 */
+                F32_ROWS(F32K_HIST_REFILL, ws - T + 1 + HOFF, ws - T + 1 + HOFF + (b + 2) * T - 1, histF);   /* refills of the last chunk */
+                if (Lc - T + 1 >= M.nLagRows) {                          /* rows of zeros: skipped (covid.h:378) */
+                    c0 = (Lc - T + 1 - M.nLagRows) / T + 1;
+                    if (c0 > b) c0 = b;
+                    Lc -= c0 * T;
+                    F32_ROWS(F32K_HIST_SKIP, ws - T + 1 + HOFF + c0 * T, ws - T + 1 + HOFF + c0 * T + 2 * T - 1, histF);
 #pragma unroll
                     for (int q = 0; q < T; ++q) {
-                        EA[q] = ek0[q * MCMC_WAVE + laneL];
-                        EB[q] = ek0[(q + T) * MCMC_WAVE + laneL];
+                        WA[q] = hbase[(c0 * T + q) * MCMC_WAVE + lane];
+                        WB[q] = hbase[(c0 * T + q + T) * MCMC_WAVE + lane];
                     }
-                    const float* ekx = ek0 + 2 * T * MCMC_WAVE;
-                    float8u_t curn = smem_rows2n(RFneg, Lc - 1);
-                    if (nch >= 2) __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0) ahead of the loop header */
+                }
+                F32_ROWS(F32K_TABLE_FIRST, Lc - 1, Lc, rowsF);
+                if (b > c0) F32_ROWS(F32K_TABLE_LAST, Lc - (b - 1 - c0) * T - T - 1, Lc, rowsF);   /* lowest row the last chunk requests */
+                float16u_t cur = smem_rows2(RFpos, Lc - 1);
+                const float* hnx = hbase + (c0 + 2) * T * MCMC_WAVE;
+                int cLo = b, cHi = b - 1;
+                if (anyE) {
+                    const int num = keLo - a0 - 2 * T + 2;
+                    cLo = num <= 0 ? 0 : (num + T - 1) / T;
+                    cHi = (keHi - a0) / T;
+                    cLo = max(cLo, c0);
+                    cHi = min(cHi, b - 1);
+                    if (cHi < cLo) { cLo = b; cHi = b - 1; }
+                }
+                const float* ek0 = ebase + cLo * T * MCMC_WAVE;
 #pragma unroll 1
-                    for (; nch >= 2; nch -= 2) {
-                        lag_chunk_fe<T>(acc, WA, WB, EA, EB, cur, curn, RFpos, RFneg, Lc, hnx, ekx, laneL);
-                        lag_chunk_fe<T>(acc, WB, WA, EB, EA, cur, curn, RFpos, RFneg, Lc - T, hnx + T * MCMC_WAVE, ekx + T * MCMC_WAVE, laneL);
-                        hnx += 2 * T * MCMC_WAVE;
-                        ekx += 2 * T * MCMC_WAVE;
-                        Lc -= 2 * T;
-                    }
-                    if (nch > 0) {
-                        lag_chunk_fe<T>(acc, WA, WB, EA, EB, cur, curn, RFpos, RFneg, Lc, hnx, ekx, laneL);
+                for (int seg = 0; seg < 3; ++seg) {
+                    int nch = (seg == 0) ? cLo - c0 : (seg == 1) ? cHi - cLo + 1 : b - 1 - cHi;
+                    pc.count(seg == 1 ? PH_NCHUNK_E : PH_NCHUNK, nch);
+                    unsigned laneL = lane;
+                    asm volatile("" : "+v"(laneL));                      /* see eval_model: nothing pending at the loop header */
+                    if (seg != 1) {
+#pragma unroll 1
+                        for (; nch >= 2; nch -= 2) {
+                            lag_chunk_f<T>(acc, WA, WB, cur, RFpos, Lc, hnx, laneL);
+                            lag_chunk_f<T>(acc, WB, WA, cur, RFpos, Lc - T, hnx + T * MCMC_WAVE, laneL);
+                            hnx += 2 * T * MCMC_WAVE;
+                            Lc -= 2 * T;
+                        }
+                        if (nch > 0) {
+                            lag_chunk_f<T>(acc, WA, WB, cur, RFpos, Lc, hnx, laneL);
 #pragma unroll
-                        for (int q = 0; q < T; ++q) { const float tmp = WA[q]; WA[q] = WB[q]; WB[q] = tmp; }
-                        hnx += T * MCMC_WAVE;
-                        Lc -= T;
+                            for (int q = 0; q < T; ++q) { const float tmp = WA[q]; WA[q] = WB[q]; WB[q] = tmp; }
+                            hnx += T * MCMC_WAVE;
+                            Lc -= T;
+                        }
+                    } else if (nch > 0) {
+                        float EA[T], EB[T];
+#pragma unroll
+                        for (int q = 0; q < T; ++q) {
+                            EA[q] = ek0[q * MCMC_WAVE + laneL];
+                            EB[q] = ek0[(q + T) * MCMC_WAVE + laneL];
+                        }
+                        const float* ekx = ek0 + 2 * T * MCMC_WAVE;
+                        float8u_t curn = smem_rows2n(RFneg, Lc - 1);
+                        if (nch >= 2) __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0) ahead of the loop header */
+#pragma unroll 1
+                        for (; nch >= 2; nch -= 2) {
+                            lag_chunk_fe<T>(acc, WA, WB, EA, EB, cur, curn, RFpos, RFneg, Lc, hnx, ekx, laneL);
+                            lag_chunk_fe<T>(acc, WB, WA, EB, EA, cur, curn, RFpos, RFneg, Lc - T, hnx + T * MCMC_WAVE, ekx + T * MCMC_WAVE, laneL);
+                            hnx += 2 * T * MCMC_WAVE;
+                            ekx += 2 * T * MCMC_WAVE;
+                            Lc -= 2 * T;
+                        }
+                        if (nch > 0) {
+                            lag_chunk_fe<T>(acc, WA, WB, EA, EB, cur, curn, RFpos, RFneg, Lc, hnx, ekx, laneL);
+#pragma unroll
+                            for (int q = 0; q < T; ++q) { const float tmp = WA[q]; WA[q] = WB[q]; WB[q] = tmp; }
+                            hnx += T * MCMC_WAVE;
+                            Lc -= T;
+                        }
+                    }
+                    pc.stamp(seg == 1 ? PH_CHUNKS_E : PH_CHUNKS);
+                }
+                request_block_inputs();
+                pc.stamp(PH_CHUNKS);
+                if (anyE && j0 - T + 1 <= keHi && j0 - 1 >= keLo)
+                    lag_tail_f<T, true>(acc, WA, RFpos, RFneg, ebase + b * T * MCMC_WAVE, lane);
+                else
+                    lag_tail_f<T, false>(acc, WA, RFpos, RFneg, nullptr, lane);
+                pc.stamp(PH_TAIL);
+                if (b > 0) {
+#pragma unroll
+                    for (int q = 0; q < T; ++q) {
+                        WA[q] = hbase[q * MCMC_WAVE + lane];
+                        WB[q] = hbase[(q + T) * MCMC_WAVE + lane];
                     }
                 }
-                pc.stamp(seg == 1 ? PH_CHUNKS_E : PH_CHUNKS);
-            }
-            /* what phase B needs from memory, requested before the tail */
-            double beh[T], pcfv[T], capv[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const int bi = min(max(j0 + t - md, 0), M.nB - 1);
-                beh[t] = B.x_u[bi * MCMC_WAVE + lane];
-                const int sg = __builtin_amdgcn_readfirstlane(lds.seg[j0 + t]);
-                const double dv = xdisc_u[max(sg, 0) * MCMC_WAVE + lane];
-                pcfv[t] = sg >= 0 ? dv : 1.0;                        /* covid.h:432-444 */
-                capv[t] = lds.capacity[j0 + t];
-            }
-            pc.stamp(PH_CHUNKS);
-            if (anyE && j0 - T + 1 <= keHi && j0 - 1 >= keLo)
-                lag_tail_f<T, true>(acc, WA, RFpos, RFneg, ebase + b * T * MCMC_WAVE, lane);
-            else
-                lag_tail_f<T, false>(acc, WA, RFpos, RFneg, nullptr, lane);
-            pc.stamp(PH_TAIL);
-            if (b > 0) {
-#pragma unroll
-                for (int q = 0; q < T; ++q) {
-                    WA[q] = hbase[q * MCMC_WAVE + lane];
-                    WB[q] = hbase[(q + T) * MCMC_WAVE + lane];
-                }
-            }
 
+            }
             /* ------------- phase B: the T days of the block, in order */
 #pragma unroll
             for (int t = 0; t < T; ++t) {
@@ -399,11 +538,13 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
                 if (i >= md && i - md < M.nData) ds_u[(i - md) * MCMC_WAVE + lane] = w * (double)acc[P_D][t].x;
                 ncur = nnf;
             }
-            if (b == 0) {
+            if constexpr (!MFMA) {
+                if (b == 0) {
 #pragma unroll
-                for (int q = 0; q < T; ++q) {
-                    WA[q] = hbase[q * MCMC_WAVE + lane];
-                    WB[q] = hbase[(q + T) * MCMC_WAVE + lane];
+                    for (int q = 0; q < T; ++q) {
+                        WA[q] = hbase[q * MCMC_WAVE + lane];
+                        WB[q] = hbase[(q + T) * MCMC_WAVE + lane];
+                    }
                 }
             }
             pc.stamp(PH_DAYS);

@@ -199,7 +199,7 @@ class CovidSampler:
     ChainManager<MetropolisChain> + DiseaseSpread + SmoothnessPrior + Target for the covid
     model (mcmc.h:1314-1655, covid.h:284-662)."""
 
-    PRECISIONS = {"f64": 0, "f32_model": 1}          # MCMC_HIP_PRECISION_*
+    PRECISIONS = {"f64": 0, "f32_model": 1, "f32_packed": 2}          # MCMC_HIP_PRECISION_*
 
     def __init__(self, cfg: dict, R, device=0, precision="f64"):
         L = lib()

@@ -1,5 +1,7 @@
 """GPU tests of the FAST arithmetic mode (MCMC_HIP_PRECISION_F32_MODEL, include/mcmc_hip.h):
-the renewal convolution of DiseaseSpread::eval in packed FP32, everything else in double.
+the renewal convolution of DiseaseSpread::eval in FP32 -- on the matrix cores ("f32_model") or, in its first
+form kept for comparison, with packed vector multiply-adds ("f32_packed") -- everything else in double.
+Every test runs in both forms.
 
 This mode is not the reference's arithmetic (`using Float = double`, mcmc.h:43), so its bar is
 not bit-exactness but the one north_star states for reduced precision: log-likelihoods close
@@ -24,12 +26,16 @@ REL, ABS = 2e-5, 2e-2
 REL_LONG_OVERFLOW = 1e-3
 
 
-def _pair(cfg, R10):
-    return H.CovidSampler(cfg, R10), H.CovidSampler(cfg, R10, precision="f32_model")
+FAST = ["f32_model", "f32_packed"]
 
 
+def _pair(cfg, R10, fast="f32_model"):
+    return H.CovidSampler(cfg, R10), H.CovidSampler(cfg, R10, precision=fast)
+
+
+@pytest.mark.parametrize("fast", FAST)
 @pytest.mark.parametrize("case", ["small", "no_prediction_days", "overflow", "c2_200_days", "long_horizon", "long_horizon_overflow"])
-def test_fast_mode_loglike_close_to_f64(R11, R10, case):
+def test_fast_mode_loglike_close_to_f64(R11, R10, case, fast):
     if case == "small":
         cfg = make_cfg(60, R11, contract=1, **SMALL)
     elif case == "no_prediction_days":             # the last block overhangs the horizon by 6 days
@@ -48,7 +54,7 @@ def test_fast_mode_loglike_close_to_f64(R11, R10, case):
     if case == "overflow":
         xs[::3, -3] *= 0.2
         xs[::3, -2] *= 0.2
-    s64, s32 = _pair(cfg, R10)
+    s64, s32 = _pair(cfg, R10, fast)
     a, b = s64.eval(xs), s32.eval(xs)
     s64.close()
     s32.close()
@@ -61,7 +67,8 @@ def test_fast_mode_loglike_close_to_f64(R11, R10, case):
     assert np.any(a[:, 0] != b[:, 0])                              # and it really is another arithmetic
 
 
-def test_fast_mode_is_deterministic_and_independent_of_the_batch(R11, R10):
+@pytest.mark.parametrize("fast", FAST)
+def test_fast_mode_is_deterministic_and_independent_of_the_batch(R11, R10, fast):
     """A chain's fast-mode result depends on its own inputs only: the wave-uniform shortcuts (common
     first day, chunks with capacity corrections) add exact zeros for the lanes they do not concern.
     Same bits for any order / composition of the batch, run after run, steps included."""
@@ -71,7 +78,7 @@ def test_fast_mode_is_deterministic_and_independent_of_the_batch(R11, R10):
     xs[::3, -2] *= 0.2
     xs[::5, -1] = 11.5                               # and very different first days
     perm = np.random.default_rng(3).permutation(130)
-    s = H.CovidSampler(cfg, R10, precision="f32_model")
+    s = H.CovidSampler(cfg, R10, precision=fast)
     a = s.eval(xs)
     assert np.array_equal(a, s.eval(xs))
     assert np.array_equal(a[perm], s.eval(xs[perm]))
@@ -86,7 +93,8 @@ def test_fast_mode_is_deterministic_and_independent_of_the_batch(R11, R10):
     s.close()
 
 
-def test_fast_mode_full_size_properties(R11, R10):
+@pytest.mark.parametrize("fast", FAST)
+def test_fast_mode_full_size_properties(R11, R10, fast):
     """BASELINE configs[2] shape (365 days, dim 358) at 16384 chains in the fast mode: a scattered
     subset run alone ends on the same bits, a repeat run is bit-identical, the log-likelihoods of the
     start points agree with the FP64 kernel's, and every chain consumed its own RNG stream."""
@@ -94,14 +102,14 @@ def test_fast_mode_full_size_properties(R11, R10):
     cfg = make_cfg(365, R11, contract=1)
     n = 16384
     xs = H.perturb_ics(CC.initial_params(cfg), n, 0.01)
-    big = H.CovidSampler(cfg, R10, precision="f32_model")
+    big = H.CovidSampler(cfg, R10, precision=fast)
     big.set_chains(xs, first_chain_id=1)
     ll0 = big.loglike().copy()
     big.step(3, 1.0, True)
     P, LL, RNG = big.params(), big.loglike(), big.rng_state()
     assert np.all(np.isfinite(LL))
     idx = np.array([0, 1, 63, 64, 4097, 9999, n - 1])
-    sub = H.CovidSampler(cfg, R10, precision="f32_model")
+    sub = H.CovidSampler(cfg, R10, precision=fast)
     sub.set_chains(xs[idx], chain_ids=idx + 1)
     sub.step(3, 1.0, True)
     assert np.array_equal(sub.params(), P[idx]) and np.array_equal(sub.loglike(), LL[idx])
@@ -117,14 +125,15 @@ def test_fast_mode_full_size_properties(R11, R10):
         s.close()
 
 
-def test_fast_mode_chains_agree_statistically(R11, R10):
+@pytest.mark.parametrize("fast", FAST)
+def test_fast_mode_chains_agree_statistically(R11, R10, fast):
     """1024 chains, same starts / chain ids / step schedule in both modes: the ensembles'
     acceptance and posterior summaries agree within Monte-Carlo error, per-step RNG use and
     pair counts are identical while the chains still coincide."""
     cfg = make_cfg(100, R11, contract=1, **SMALL)
     xs = perturbed(cfg, 1024, 0.02)
     out = {}
-    for name, s in zip(("f64", "f32"), _pair(cfg, R10)):
+    for name, s in zip(("f64", "f32"), _pair(cfg, R10, fast)):
         s.set_chains(xs)
         s.step(1, 1.0, True)
         first = (s.rng_state().copy(), s.pair_count())
@@ -151,8 +160,9 @@ def test_fast_mode_chains_agree_statistically(R11, R10):
 
 def test_fast_mode_needs_fma_contraction_and_a_known_mode(R11, R10):
     s = H.CovidSampler(make_cfg(40, R11, contract=0, **SMALL), R10)
-    with pytest.raises(RuntimeError, match="contract"):
-        s.set_precision("f32_model")
+    for fast in FAST:
+        with pytest.raises(RuntimeError, match="contract"):
+            s.set_precision(fast)
     with pytest.raises(RuntimeError, match="unknown mode"):
         H._check(H.lib().mcmc_hip_set_precision(s._h, 7))
     s.close()
@@ -164,7 +174,7 @@ def test_zz_row_checks_of_a_diagnosis_build_are_clean(R11, R10):
     violation; the tests above have run in this process, so the record covers them.  The product build
     compiles the checks out and always reports zeros."""
     cfg = make_cfg(60, R11, contract=1, **SMALL)
-    s = H.CovidSampler(cfg, R10, precision="f32_model")
+    s = H.CovidSampler(cfg, R10, precision="f32_packed")
     s.eval(perturbed(cfg, 70, 0.1))
     kind, lo, hi, bound = s.f32_check()
     s.close()
