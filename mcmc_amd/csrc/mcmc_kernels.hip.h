@@ -212,8 +212,8 @@ struct LdsView {
     const int* seg;           /* [simPad] */
     /* fast mode on the matrix cores only (stage_lds_f32, mcmc_model_f32.hip.h); null otherwise */
     const float* tabF;        /* [F32_TAB_PAD + rowsL][8] float response table, F32_TAB_PAD rows of zeros in front */
-    const float* tabN;        /* same shape: the capacity-correction columns (0 0 0 0 -SFS -RFS 1-DFS 0) */
-    float* tr;                /* [waves of the workgroup][64][65] transposition buffers */
+    const float* tabN;        /* [F32_TAB_PAD + rowsL][4] capacity-correction table (-SFS -RFS 1-DFS 0), padded alike */
+    float* tr;                /* [waves of the workgroup][64][65 + 33] transposition buffers */
 };
 
 __host__ __device__ inline int lds_rows(const DevModel& M, bool derive, int T) {
@@ -256,18 +256,18 @@ __device__ inline LdsView stage_lds(const DevModel& M, double* lds, bool derive,
 
 /* LDS image of the fast mode on the matrix cores: no double tables (its sequential part takes rows 0..7
  * through the scalar cache), the per-day constants as above, the two float tables the MFMA B operands are
- * read from, and one 64 x 65 float transposition buffer per wave.  Lags reach horizon + 7 (day j0 + 7 of the
+ * read from, and per wave a 64 x 65 and a 64 x 33 float transposition buffer.  Lags reach horizon + 7 (day j0 + 7 of the
  * last block against the wave's first day); sources all of whose lags are >= nLagRows are skipped in blocks
  * of 8 days, so no row above nLagRows + 13 is read either. */
 #define F32_TAB_PAD 2         /* the B operand of the pair after the last one is requested too: rows 0 and -1 */
-#define F32_TR_FLOATS (MCMC_WAVE * 65)
+#define F32_TR_FLOATS (MCMC_WAVE * (65 + 33))
 __host__ __device__ inline int lds_rows_f32(const DevModel& M) {
     const int a = M.simDays + 8, b = M.nLagRows + 16;
     return a < b ? a : b;
 }
 __host__ __device__ inline size_t lds_bytes_f32(const DevModel& M) {
     return sizeof(double) * ((size_t)M.simPad + 2 * (size_t)M.nData) + sizeof(int) * (size_t)(M.simPad + (M.simPad & 1)) +
-           sizeof(float) * ((size_t)2 * (F32_TAB_PAD + lds_rows_f32(M)) * 8 + (size_t)MCMC_WAVES_PER_BLOCK * F32_TR_FLOATS) + 16;
+           sizeof(float) * ((size_t)(F32_TAB_PAD + lds_rows_f32(M)) * 12 + (size_t)MCMC_WAVES_PER_BLOCK * F32_TR_FLOATS) + 16;
 }
 __device__ inline LdsView stage_lds_f32(const DevModel& M, double* lds) {
     const int rows = lds_rows_f32(M);
@@ -277,7 +277,7 @@ __device__ inline LdsView stage_lds_f32(const DevModel& M, double* lds) {
     int* seg = (int*)(sg2 + M.nData);
     float* tf = (float*)(seg + M.simPad + (M.simPad & 1));
     float* tn = tf + (size_t)(F32_TAB_PAD + rows) * 8;
-    float* tr = tn + (size_t)(F32_TAB_PAD + rows) * 8;
+    float* tr = tn + (size_t)(F32_TAB_PAD + rows) * 4;
     for (int i = threadIdx.x; i < M.simPad; i += blockDim.x) {
         cap[i] = M.capacity[i];
         seg[i] = M.seg[i];
@@ -286,11 +286,10 @@ __device__ inline LdsView stage_lds_f32(const DevModel& M, double* lds) {
         dea[i] = M.deaths[i];
         sg2[i] = M.sigma2[i];
     }
-    for (int i = threadIdx.x; i < (F32_TAB_PAD + rows) * 8; i += blockDim.x) {
-        const int r = i / 8 - F32_TAB_PAD, c = i % 8;
-        tf[i] = r >= 0 ? M.RF[r * 8 + c] : 0.0f;
-        tn[i] = (r >= 0 && c >= 4 && c < 7) ? M.RFn[r * 4 + (c - 4)] : 0.0f;
-    }
+    for (int i = threadIdx.x; i < (F32_TAB_PAD + rows) * 8; i += blockDim.x)
+        tf[i] = i >= F32_TAB_PAD * 8 ? M.RF[i - F32_TAB_PAD * 8] : 0.0f;
+    for (int i = threadIdx.x; i < (F32_TAB_PAD + rows) * 4; i += blockDim.x)
+        tn[i] = i >= F32_TAB_PAD * 4 ? M.RFn[i - F32_TAB_PAD * 4] : 0.0f;
     __syncthreads();
     LdsView v;
     v.Rpos = nullptr; v.Rneg = nullptr; v.capacity = cap; v.deaths = dea; v.sigma2 = sg2; v.seg = seg;

@@ -189,51 +189,77 @@ __device__ __forceinline__ void lag_tail_f(float2_t (&acc)[P_N][T], const float 
 /* ------------------------------------------------------------ phase A on the matrix cores ---- */
 typedef float float16v_t __attribute__((ext_vector_type(16)));
 
-/* Streams nPairs pairs of source days (a multiple of GRAN) through the four accumulator tiles.  hp: the
- * lane's A pointer of pair 0 (row k0 + lane/32, chain lane%32 of the float history; +32 = the other chain
- * half; a pair on = +128 floats); li: the lane's LDS index of pair 0's B value for days j0..j0+3 (+32: days
- * j0+4..j0+7; a pair on = -16).  RING pairs of A values are in flight; the B values of the NEXT pair are
- * requested ahead of the current pair's MFMAs, which block the wave's issue for 64 cycles each.  Reads ahead
- * of the last pair stay inside the history buffer (rows < j0 + 2 RING + 2) and the table's pad rows. */
-template <int RING, int GRAN>
-__device__ __forceinline__ void mfma_stream(float16v_t (&C)[2][2], const float* hp, const float* tab, int li, int nPairs) {
+/* Streams nPairs pairs of source days through 2 x NT accumulator tiles.  hp: the lane's
+ * A pointer of pair 0 (row k0 + lane/32, chain lane%32 of the float history; +32 = the other chain half; a
+ * pair on = +128 floats).  li: the lane's LDS index of pair 0's B value.  NT = 2 (response table, 8 floats
+ * per lag: tile 0 = days j0..j0+3, tile 1 at li + 32 = days j0+4..j0+7; a pair on = -16) or NT = 1 (correction
+ * table, 4 floats per lag: one tile = 8 days x 4; a pair on = -8).  RING pairs of A values are in flight; the B
+ * values of the NEXT pair are requested ahead of the current pair's MFMAs, which block the wave's issue for
+ * 64 cycles each.  Reads ahead of the last pair stay inside the history buffer (rows < j0 + 2 RING + 2) and
+ * the table's pad rows. */
+template <int RING, int NT>
+__device__ __forceinline__ void mfma_stream(float16v_t (&C)[2][NT], const float* hp, const float* tab, int li, int nPairs) {
+    constexpr int BSTEP = NT == 2 ? 16 : 8;
     float ra[RING][2];
 #pragma unroll
     for (int u = 0; u < RING; ++u) {
         ra[u][0] = hp[u * 128];
         ra[u][1] = hp[u * 128 + 32];
     }
-    float b0 = tab[li], b1 = tab[li + 32];
+    float bv[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) bv[q] = tab[li + 32 * q];
     const float* hq = hp + RING * 128;
     int rem = nPairs;
-    while (rem > 0) {
+    /* whole rings: the loop has ONE entry and ONE back edge and 2 RING loads are in flight at both, so the
+     * wait ahead of slot u's MFMAs is exactly "all but the 2 RING - 2 younger loads" (an early exit inside the
+     * unrolled body makes the wait-count pass assume the worst path and drain the ring to a quarter) */
+#pragma unroll 1
+    for (; rem >= RING; rem -= RING) {
 #pragma unroll
         for (int u = 0; u < RING; ++u) {
-            if (u % GRAN == 0 && u > 0) {
-                if (rem <= 0) break;
-            }
-            li -= 16;
-            const float nb0 = tab[li];
-            const float nb1 = tab[li + 32];
+            li -= BSTEP;
+            float nb[NT];
+#pragma unroll
+            for (int q = 0; q < NT; ++q) nb[q] = tab[li + 32 * q];
             __builtin_amdgcn_sched_barrier(0);
             const float a0 = ra[u][0], a1 = ra[u][1];
-            C[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, C[0][0], 0, 0, 0);
-            C[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, C[0][1], 0, 0, 0);
-            C[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, C[1][0], 0, 0, 0);
-            C[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, C[1][1], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) C[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[q], C[0][q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) C[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[q], C[1][q], 0, 0, 0);
             ra[u][0] = hq[u * 128];
             ra[u][1] = hq[u * 128 + 32];
-            b0 = nb0;
-            b1 = nb1;
+#pragma unroll
+            for (int q = 0; q < NT; ++q) bv[q] = nb[q];
             __builtin_amdgcn_sched_barrier(0);
-            if (u % GRAN == GRAN - 1) rem -= GRAN;
         }
         hq += RING * 128;
     }
+    /* the last rem < RING pairs are in the ring already: no refills */
+#pragma unroll
+    for (int u = 0; u < RING - 1; ++u) {
+        if (rem <= u) break;
+        li -= BSTEP;
+        float nb[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) nb[q] = tab[li + 32 * q];
+        __builtin_amdgcn_sched_barrier(0);
+        const float a0 = ra[u][0], a1 = ra[u][1];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) C[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[q], C[0][q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) C[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[q], C[1][q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) bv[q] = nb[q];
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
-/* All sources before the block (days kLo .. j0-1, kLo = ws + a multiple of 8) for the block's 8 days, the
- * capacity corrections of the source days [eLo, eHi] among them, and the hand-over to chain-per-lane. */
+/* All sources before the block (days kLo .. j0-1; ws, kLo and j0 are multiples of 8) for the block's 8 days,
+ * the capacity corrections of the source days [eLo, eHi] among them, and the hand-over to chain-per-lane.
+ * The corrections touch three curves only, so their B tile is 8 days x (-SFS, -RFS, 1-DFS, 0): one N tile
+ * covers the whole block and a pair costs two MFMAs, not four. */
 template <int T>
 __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsView& lds, float* tr, const float* hn_u,
                                              const float* he_u, int ws, int j0, int kLo, int eLo, int eHi,
@@ -251,18 +277,27 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
     {
         const float* hp = hn_u + (kLo + half + HOFF) * MCMC_WAVE + n;
         const int li = (j0 - kLo - half + F32_TAB_PAD) * 8 + n;
-        mfma_stream<16, 4>(C, hp, lds.tabF, li, (j0 - kLo) / 2);
+        mfma_stream<16, 2>(C, hp, lds.tabF, li, (j0 - kLo) / 2);
     }
     pc.stamp(PH_CHUNKS);
-    if (eHi >= eLo) {
-        /* pairs are aligned to ws; those touching [eLo, eHi], not before kLo, not into the block */
-        int pLo = (max(eLo, kLo) - ws) / 2, pHi = min((eHi - ws) / 2, (j0 - ws) / 2 - 1);
-        if (pHi >= pLo) {
-            const int k0 = ws + 2 * pLo;
-            const float* hp = he_u + (k0 + half + HOFF) * MCMC_WAVE + n;
-            const int li = (j0 - k0 - half + F32_TAB_PAD) * 8 + n;
-            mfma_stream<4, 1>(C, hp, lds.tabN, li, pHi - pLo + 1);
-        }
+    float* tr2 = tr + MCMC_WAVE * 65;                   /* [64][33]: the corrections' 8 days x 4 */
+    /* pairs are aligned to even days; those touching [eLo, eHi], not before kLo, not into the block */
+    const int pLo = (max(eLo, kLo) - ws) / 2, pHi = min((eHi - ws) / 2, (j0 - ws) / 2 - 1);
+    const bool withE = eHi >= eLo && pHi >= pLo;
+    if (withE) {
+        float16v_t Ce[2][1];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Ce[a][0][i] = 0.0f;
+        const int k0 = ws + 2 * pLo;
+        const float* hp = he_u + (k0 + half + HOFF) * MCMC_WAVE + n;
+        const int li = (j0 - k0 - half + F32_TAB_PAD) * 4 + n;
+        mfma_stream<8, 1>(Ce, hp, lds.tabN, li, pHi - pLo + 1);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) tr2[(32 * mt + 8 * (v / 4) + 4 * half + (v % 4)) * 33 + n] = Ce[mt][0][v];
     }
     pc.stamp(PH_CHUNKS_E);
     /* MFMA layout -> chain per lane: element v of tile (mt, nt) is chain 32 mt + 8 (v/4) + 4 half + v%4,
@@ -281,6 +316,14 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int c = 0; c < P_N; ++c) acc[c][t] = float2_t{mine[t * 8 + 2 * c], mine[t * 8 + 2 * c + 1]};
+    if (withE) {
+        const float* mine2 = tr2 + lane * 33;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            acc[P_SR][t] += float2_t{mine2[t * 4], mine2[t * 4 + 1]};
+            acc[P_D][t].x += mine2[t * 4 + 2];
+        }
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);                 /* read back before the next block overwrites the buffer */
     __builtin_amdgcn_wave_barrier();
     pc.stamp(PH_TAIL);
