@@ -197,15 +197,19 @@ typedef float float16v_t __attribute__((ext_vector_type(16)));
  * values of the NEXT pair are requested ahead of the current pair's MFMAs, which block the wave's issue for
  * 64 cycles each.  Reads ahead of the last pair stay inside the history buffer (rows < j0 + 2 RING + 2) and
  * the table's pad rows. */
+/* The A values of a pair: the lane's row (k0 + lane/32) of the float history, chains 2n and 2n+1 (n = lane%32)
+ * in one 8-byte load -- chain tile 0 holds the even chains of the wave, tile 1 the odd ones. */
+__device__ __forceinline__ void ld_pair(float (&a)[2], const float* p) {
+    const float2_t t = *(const float2_t*)p;
+    a[0] = t.x;
+    a[1] = t.y;
+}
 template <int RING, int NT>
 __device__ __forceinline__ void mfma_stream(float16v_t (&C)[2][NT], const float* hp, const float* tab, int li, int nPairs) {
     constexpr int BSTEP = NT == 2 ? 16 : 8;
     float ra[RING][2];
 #pragma unroll
-    for (int u = 0; u < RING; ++u) {
-        ra[u][0] = hp[u * 128];
-        ra[u][1] = hp[u * 128 + 32];
-    }
+    for (int u = 0; u < RING; ++u) ld_pair(ra[u], hp + u * 128);
     float bv[NT];
 #pragma unroll
     for (int q = 0; q < NT; ++q) bv[q] = tab[li + 32 * q];
@@ -216,8 +220,30 @@ __device__ __forceinline__ void mfma_stream(float16v_t (&C)[2][NT], const float*
      * unrolled body makes the wait-count pass assume the worst path and drain the ring to a quarter) */
 #pragma unroll 1
     for (; rem >= RING; rem -= RING) {
+        const float* tb = tab + (li - RING * BSTEP);         /* B of the pair after this ring: >= the pad rows */
 #pragma unroll
         for (int u = 0; u < RING; ++u) {
+            float nb[NT];
+#pragma unroll
+            for (int q = 0; q < NT; ++q) nb[q] = tb[(RING - 1 - u) * BSTEP + 32 * q];
+            __builtin_amdgcn_sched_barrier(0);
+            const float a0 = ra[u][0], a1 = ra[u][1];
+#pragma unroll
+            for (int q = 0; q < NT; ++q) C[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[q], C[0][q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) C[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[q], C[1][q], 0, 0, 0);
+            ld_pair(ra[u], hq + u * 128);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) bv[q] = nb[q];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        hq += RING * 128;
+        li -= RING * BSTEP;
+    }
+    /* the last rem < RING pairs are in the ring already: no refills */
+#pragma unroll
+    for (int u = 0; u < RING - 1; ++u) {
+        if (u < rem) {                                    /* no `break`: the loop stays unrolled, the ring in registers */
             li -= BSTEP;
             float nb[NT];
 #pragma unroll
@@ -228,31 +254,10 @@ __device__ __forceinline__ void mfma_stream(float16v_t (&C)[2][NT], const float*
             for (int q = 0; q < NT; ++q) C[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[q], C[0][q], 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < NT; ++q) C[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[q], C[1][q], 0, 0, 0);
-            ra[u][0] = hq[u * 128];
-            ra[u][1] = hq[u * 128 + 32];
 #pragma unroll
             for (int q = 0; q < NT; ++q) bv[q] = nb[q];
             __builtin_amdgcn_sched_barrier(0);
         }
-        hq += RING * 128;
-    }
-    /* the last rem < RING pairs are in the ring already: no refills */
-#pragma unroll
-    for (int u = 0; u < RING - 1; ++u) {
-        if (rem <= u) break;
-        li -= BSTEP;
-        float nb[NT];
-#pragma unroll
-        for (int q = 0; q < NT; ++q) nb[q] = tab[li + 32 * q];
-        __builtin_amdgcn_sched_barrier(0);
-        const float a0 = ra[u][0], a1 = ra[u][1];
-#pragma unroll
-        for (int q = 0; q < NT; ++q) C[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[q], C[0][q], 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < NT; ++q) C[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[q], C[1][q], 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < NT; ++q) bv[q] = nb[q];
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -275,7 +280,7 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
 #pragma unroll
             for (int i = 0; i < 16; ++i) C[a][b][i] = 0.0f;
     {
-        const float* hp = hn_u + (kLo + half + HOFF) * MCMC_WAVE + n;
+        const float* hp = hn_u + (kLo + half + HOFF) * MCMC_WAVE + 2 * n;
         const int li = (j0 - kLo - half + F32_TAB_PAD) * 8 + n;
         mfma_stream<16, 2>(C, hp, lds.tabF, li, (j0 - kLo) / 2);
     }
@@ -291,16 +296,16 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
 #pragma unroll
             for (int i = 0; i < 16; ++i) Ce[a][0][i] = 0.0f;
         const int k0 = ws + 2 * pLo;
-        const float* hp = he_u + (k0 + half + HOFF) * MCMC_WAVE + n;
+        const float* hp = he_u + (k0 + half + HOFF) * MCMC_WAVE + 2 * n;
         const int li = (j0 - k0 - half + F32_TAB_PAD) * 4 + n;
         mfma_stream<8, 1>(Ce, hp, lds.tabN, li, pHi - pLo + 1);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) tr2[(32 * mt + 8 * (v / 4) + 4 * half + (v % 4)) * 33 + n] = Ce[mt][0][v];
+            for (int v = 0; v < 16; ++v) tr2[(2 * (8 * (v / 4) + 4 * half + (v % 4)) + mt) * 33 + n] = Ce[mt][0][v];
     }
     pc.stamp(PH_CHUNKS_E);
-    /* MFMA layout -> chain per lane: element v of tile (mt, nt) is chain 32 mt + 8 (v/4) + 4 half + v%4,
+    /* MFMA layout -> chain per lane: element v of tile (mt, nt) is chain 2 (8 (v/4) + 4 half + v%4) + mt,
      * column 32 nt + n (= day 4 nt + n/8, curve n%8) */
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -308,7 +313,7 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int v = 0; v < 16; ++v)
-                tr[(32 * mt + 8 * (v / 4) + 4 * half + (v % 4)) * 65 + 32 * nt + n] = C[mt][nt][v];
+                tr[(2 * (8 * (v / 4) + 4 * half + (v % 4)) + mt) * 65 + 32 * nt + n] = C[mt][nt][v];
     __builtin_amdgcn_s_waitcnt(0xc07f);                 /* lgkmcnt(0): the wave's own LDS writes have landed */
     __builtin_amdgcn_wave_barrier();
     const float* mine = tr + lane * 65;
