@@ -213,7 +213,7 @@ struct LdsView {
     /* fast mode on the matrix cores only (stage_lds_f32, mcmc_model_f32.hip.h); null otherwise */
     const float* tabF;        /* [F32_TAB_PAD + rowsL][8] float response table, F32_TAB_PAD rows of zeros in front */
     const float* tabN;        /* [F32_TAB_PAD + rowsL][4] capacity-correction table (-SFS -RFS 1-DFS 0), padded alike */
-    float* tr;                /* [waves of the workgroup][64][65 + 33] transposition buffers */
+    float* tr;                /* [waves of the workgroup][64][F32_TR_ROW + F32_TR2_ROW] transposition buffers */
 };
 
 __host__ __device__ inline int lds_rows(const DevModel& M, bool derive, int T) {
@@ -256,17 +256,21 @@ __device__ inline LdsView stage_lds(const DevModel& M, double* lds, bool derive,
 
 /* LDS image of the fast mode on the matrix cores: no double tables (its sequential part takes rows 0..7
  * through the scalar cache), the per-day constants as above, the two float tables the MFMA B operands are
- * read from, and per wave a 64 x 65 and a 64 x 33 float transposition buffer.  Lags reach horizon + 7 (day j0 + 7 of the
+ * read from, and per wave a 64 x 68 and a 64 x 36 float transposition buffer.  Lags reach horizon + 7 (day j0 + 7 of the
  * last block against the wave's first day); sources all of whose lags are >= nLagRows are skipped in blocks
  * of 8 days, so no row above nLagRows + 13 is read either. */
 #define F32_TAB_PAD 2         /* the B operand of the pair after the last one is requested too: rows 0 and -1 */
-#define F32_TR_FLOATS (MCMC_WAVE * (65 + 33))
+#define F32_TR_ROW 68          /* floats per chain of the 8 days x 8 curves buffer (64 used) */
+#define F32_TR2_ROW 36         /* ... of the 8 days x 4 corrections buffer (32 used) */
+#define F32_TR_FLOATS (MCMC_WAVE * (F32_TR_ROW + F32_TR2_ROW))
 __host__ __device__ inline int lds_rows_f32(const DevModel& M) {
     const int a = M.simDays + 8, b = M.nLagRows + 16;
     return a < b ? a : b;
 }
 __host__ __device__ inline size_t lds_bytes_f32(const DevModel& M) {
-    return sizeof(double) * ((size_t)M.simPad + 2 * (size_t)M.nData) + sizeof(int) * (size_t)(M.simPad + (M.simPad & 1)) +
+    /* every part starts 16-byte aligned (the transposition buffers are read 16 bytes at a time) */
+    const size_t nd = ((size_t)M.simPad + 2 * (size_t)M.nData + 1) & ~(size_t)1, ni = ((size_t)M.simPad + 3) & ~(size_t)3;
+    return sizeof(double) * nd + sizeof(int) * ni +
            sizeof(float) * ((size_t)(F32_TAB_PAD + lds_rows_f32(M)) * 12 + (size_t)MCMC_WAVES_PER_BLOCK * F32_TR_FLOATS) + 16;
 }
 __device__ inline LdsView stage_lds_f32(const DevModel& M, double* lds) {
@@ -274,8 +278,8 @@ __device__ inline LdsView stage_lds_f32(const DevModel& M, double* lds) {
     double* cap = lds;
     double* dea = cap + M.simPad;
     double* sg2 = dea + M.nData;
-    int* seg = (int*)(sg2 + M.nData);
-    float* tf = (float*)(seg + M.simPad + (M.simPad & 1));
+    int* seg = (int*)(lds + (((size_t)M.simPad + 2 * (size_t)M.nData + 1) & ~(size_t)1));
+    float* tf = (float*)(seg + (((size_t)M.simPad + 3) & ~(size_t)3));
     float* tn = tf + (size_t)(F32_TAB_PAD + rows) * 8;
     float* tr = tn + (size_t)(F32_TAB_PAD + rows) * 4;
     for (int i = threadIdx.x; i < M.simPad; i += blockDim.x) {

@@ -285,7 +285,7 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
         mfma_stream<16, 2>(C, hp, lds.tabF, li, (j0 - kLo) / 2);
     }
     pc.stamp(PH_CHUNKS);
-    float* tr2 = tr + MCMC_WAVE * 65;                   /* [64][33]: the corrections' 8 days x 4 */
+    float* tr2 = tr + MCMC_WAVE * F32_TR_ROW;           /* [64][F32_TR2_ROW]: the corrections' 8 days x 4 */
     /* pairs are aligned to even days; those touching [eLo, eHi], not before kLo, not into the block */
     const int pLo = (max(eLo, kLo) - ws) / 2, pHi = min((eHi - ws) / 2, (j0 - ws) / 2 - 1);
     const bool withE = eHi >= eLo && pHi >= pLo;
@@ -302,7 +302,7 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) tr2[(2 * (8 * (v / 4) + 4 * half + (v % 4)) + mt) * 33 + n] = Ce[mt][0][v];
+            for (int v = 0; v < 16; ++v) tr2[(2 * (8 * (v / 4) + 4 * half + (v % 4)) + mt) * F32_TR2_ROW + n] = Ce[mt][0][v];
     }
     pc.stamp(PH_CHUNKS_E);
     /* MFMA layout -> chain per lane: element v of tile (mt, nt) is chain 2 (8 (v/4) + 4 half + v%4) + mt,
@@ -313,20 +313,27 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int v = 0; v < 16; ++v)
-                tr[(2 * (8 * (v / 4) + 4 * half + (v % 4)) + mt) * 65 + 32 * nt + n] = C[mt][nt][v];
+                tr[(2 * (8 * (v / 4) + 4 * half + (v % 4)) + mt) * F32_TR_ROW + 32 * nt + n] = C[mt][nt][v];
     __builtin_amdgcn_s_waitcnt(0xc07f);                 /* lgkmcnt(0): the wave's own LDS writes have landed */
     __builtin_amdgcn_wave_barrier();
-    const float* mine = tr + lane * 65;
+    /* rows of 68 / 36 floats: 16-byte aligned, so a day's eight sums come back as two 16-byte reads (lanes
+     * 8 apart share a bank group, which a 16-byte read of 64 lanes needs eight passes for anyway) */
+    const float4_t* mine = (const float4_t*)(tr + lane * F32_TR_ROW);
 #pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int c = 0; c < P_N; ++c) acc[c][t] = float2_t{mine[t * 8 + 2 * c], mine[t * 8 + 2 * c + 1]};
+    for (int t = 0; t < T; ++t) {
+        const float4_t lo = mine[2 * t], hi = mine[2 * t + 1];
+        acc[P_INF][t] = float2_t{lo[0], lo[1]};
+        acc[P_IM][t] = float2_t{lo[2], lo[3]};
+        acc[P_SR][t] = float2_t{hi[0], hi[1]};
+        acc[P_D][t] = float2_t{hi[2], hi[3]};
+    }
     if (withE) {
-        const float* mine2 = tr2 + lane * 33;
+        const float4_t* mine2 = (const float4_t*)(tr2 + lane * F32_TR2_ROW);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            acc[P_SR][t] += float2_t{mine2[t * 4], mine2[t * 4 + 1]};
-            acc[P_D][t].x += mine2[t * 4 + 2];
+            const float4_t e4 = mine2[t];
+            acc[P_SR][t] += float2_t{e4[0], e4[1]};
+            acc[P_D][t].x += e4[2];
         }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);                 /* read back before the next block overwrites the buffer */
