@@ -355,7 +355,7 @@ def main():
             "value": value, "unit": "MH steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 packed (renewal convolution) + f64 -- FAST MODE, not the headline metric" if fast_main else "f64",
+            "dtype": ("f32 %s (renewal convolution) + f64 -- FAST MODE, not the headline metric" % ("MFMA" if args.precision == "f32_model" else "packed FMA")) if fast_main else "f64",
             "data": "synthetic",
             "config": {"workload": (f"multi-region covid.h model (extension), {args.regions} regions x {n_data} data days, "
                                     f"{n_chains} independent chains per GPU, systematic scan over the regions, chain-sharded "
@@ -413,7 +413,7 @@ def main():
                                   "parity": "bit-exact against the oracle built with contract=0 (tests/test_gpu_parity.py)"})
         if side and args.contract and not args.no_fast_leg:
             out["fp32_fast_mode"] = side_leg(cfg, R, device, adapted, first_id, args, "f32_model", 1)
-            out["fp32_fast_mode"].update({"dtype": "f32 packed (renewal convolution) + f64 (everything else)",
+            out["fp32_fast_mode"].update({"dtype": "f32 MFMA v_mfma_f32_32x32x2_f32 (renewal convolution) + f64 (everything else)",
                                           "peak": PEAK_FP32_VECTOR_TFLOPS,
                                           "frac": out["fp32_fast_mode"]["achieved"] / PEAK_FP32_VECTOR_TFLOPS,
                                           "speedup_over_f64": out["fp32_fast_mode"]["value"] / value,

@@ -194,9 +194,9 @@ typedef float float16v_t __attribute__((ext_vector_type(16)));
  * pair on = +128 floats).  li: the lane's LDS index of pair 0's B value.  NT = 2 (response table, 8 floats
  * per lag: tile 0 = days j0..j0+3, tile 1 at li + 32 = days j0+4..j0+7; a pair on = -16) or NT = 1 (correction
  * table, 4 floats per lag: one tile = 8 days x 4; a pair on = -8).  RING pairs of A values are in flight; the B
- * values of the NEXT pair are requested ahead of the current pair's MFMAs, which block the wave's issue for
- * 64 cycles each.  Reads ahead of the last pair stay inside the history buffer (rows < j0 + 2 RING + 2) and
- * the table's pad rows. */
+ * values of the NEXT pair are requested ahead of the current pair's MFMAs.  The ring is refilled
+ * unconditionally (conditional refills cost the exact wait counts): reads ahead of the last pair stay inside
+ * the history buffer (rows < j0 + 2 RING + 2) and the table's pad rows and are never used. */
 /* The A values of a pair: the lane's row (k0 + lane/32) of the float history, chains 2n and 2n+1 (n = lane%32)
  * in one 8-byte load -- chain tile 0 holds the even chains of the wave, tile 1 the odd ones. */
 __device__ __forceinline__ void ld_pair(float (&a)[2], const float* p) {
@@ -204,12 +204,16 @@ __device__ __forceinline__ void ld_pair(float (&a)[2], const float* p) {
     a[0] = t.x;
     a[1] = t.y;
 }
-template <int RING, int NT>
-__device__ __forceinline__ void mfma_stream(float16v_t (&C)[2][NT], const float* hp, const float* tab, int li, int nPairs) {
-    constexpr int BSTEP = NT == 2 ? 16 : 8;
-    float ra[RING][2];
+template <int RING>
+__device__ __forceinline__ void mfma_ring_load(float (&ra)[RING][2], const float* hp) {
 #pragma unroll
     for (int u = 0; u < RING; ++u) ld_pair(ra[u], hp + u * 128);
+}
+/* `ra`: the first RING pairs (mfma_ring_load, possibly issued long before, or a copy kept from an earlier block) */
+template <int RING, int NT>
+__device__ __forceinline__ void mfma_stream(float16v_t (&C)[2][NT], float (&ra)[RING][2], const float* hp, const float* tab,
+                                            int li, int nPairs) {
+    constexpr int BSTEP = NT == 2 ? 16 : 8;
     float bv[NT];
 #pragma unroll
     for (int q = 0; q < NT; ++q) bv[q] = tab[li + 32 * q];
@@ -265,10 +269,12 @@ __device__ __forceinline__ void mfma_stream(float16v_t (&C)[2][NT], const float*
  * the capacity corrections of the source days [eLo, eHi] among them, and the hand-over to chain-per-lane.
  * The corrections touch three curves only, so their B tile is 8 days x (-SFS, -RFS, 1-DFS, 0): one N tile
  * covers the whole block and a pair costs two MFMAs, not four. */
+#define F32_RING 16           /* pairs of history values in flight in the main stream */
+#define F32_RING_E 8          /* ... in the corrections' stream */
 template <int T>
 __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsView& lds, float* tr, const float* hn_u,
                                              const float* he_u, int ws, int j0, int kLo, int eLo, int eHi,
-                                             unsigned lane, PhaseClock& pc) {
+                                             float (&ring0)[F32_RING][2], bool& haveRing0, unsigned lane, PhaseClock& pc) {
     static_assert(T == 8, "one block = 2 x 32 MFMA columns = 8 days x 8 curves");
     constexpr int HOFF = 2 * T;
     const int half = (int)(lane >> 5), n = (int)(lane & 31);
@@ -279,26 +285,44 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) C[a][b][i] = 0.0f;
+    /* pairs are aligned to even days; the corrections' are those touching [eLo, eHi], not before kLo, not into
+     * the block.  Their first ring is requested before the main stream, which hides the round trip. */
+    const int pLo = (max(eLo, kLo) - ws) / 2, pHi = min((eHi - ws) / 2, (j0 - ws) / 2 - 1);
+    const bool withE = eHi >= eLo && pHi >= pLo;
+    const int kE = withE ? ws + 2 * pLo : ws;
+    const float* hpe = he_u + (kE + half + HOFF) * MCMC_WAVE + 2 * n;
+    float re[F32_RING_E][2];
+    if (withE) mfma_ring_load<F32_RING_E>(re, hpe);
     {
+        /* Without lag skipping every block of a pass starts its stream with the SAME 32 history rows
+         * (ws .. ws+31): once they all lie before the block a copy stays in registers and the later blocks
+         * start without a memory round trip. */
         const float* hp = hn_u + (kLo + half + HOFF) * MCMC_WAVE + 2 * n;
         const int li = (j0 - kLo - half + F32_TAB_PAD) * 8 + n;
-        mfma_stream<16, 2>(C, hp, lds.tabF, li, (j0 - kLo) / 2);
+        float ra[F32_RING][2];
+        if (haveRing0 && kLo == ws) {
+#pragma unroll
+            for (int u = 0; u < F32_RING; ++u) { ra[u][0] = ring0[u][0]; ra[u][1] = ring0[u][1]; }
+        } else {
+            mfma_ring_load<F32_RING>(ra, hp);
+            if (kLo == ws && j0 - ws >= 2 * F32_RING) {
+#pragma unroll
+                for (int u = 0; u < F32_RING; ++u) { ring0[u][0] = ra[u][0]; ring0[u][1] = ra[u][1]; }
+                haveRing0 = true;
+            }
+        }
+        mfma_stream<F32_RING, 2>(C, ra, hp, lds.tabF, li, (j0 - kLo) / 2);
     }
     pc.stamp(PH_CHUNKS);
     float* tr2 = tr + MCMC_WAVE * F32_TR_ROW;           /* [64][F32_TR2_ROW]: the corrections' 8 days x 4 */
-    /* pairs are aligned to even days; those touching [eLo, eHi], not before kLo, not into the block */
-    const int pLo = (max(eLo, kLo) - ws) / 2, pHi = min((eHi - ws) / 2, (j0 - ws) / 2 - 1);
-    const bool withE = eHi >= eLo && pHi >= pLo;
     if (withE) {
         float16v_t Ce[2][1];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int i = 0; i < 16; ++i) Ce[a][0][i] = 0.0f;
-        const int k0 = ws + 2 * pLo;
-        const float* hp = he_u + (k0 + half + HOFF) * MCMC_WAVE + 2 * n;
-        const int li = (j0 - k0 - half + F32_TAB_PAD) * 4 + n;
-        mfma_stream<8, 1>(Ce, hp, lds.tabN, li, pHi - pLo + 1);
+        const int li = (j0 - kE - half + F32_TAB_PAD) * 4 + n;
+        mfma_stream<F32_RING_E, 1>(Ce, re, hpe, lds.tabN, li, pHi - pLo + 1);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -423,6 +447,8 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
         }
         pc.stamp(PH_SETUP);
         double* ds_u = B.d1s_u + (shift == 1 ? 0 : M.nData * MCMC_WAVE);
+        [[maybe_unused]] float ring0[MFMA ? F32_RING : 1][2];       /* mfma_sources: the stream's first history rows */
+        [[maybe_unused]] bool haveRing0 = false;
 
 #pragma unroll 1
         for (int j0 = ws; j0 < horizon; j0 += T) {
@@ -457,7 +483,7 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
                 request_block_inputs();
                 if (j0 > kLo) {
                     const int waveInBlock = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / MCMC_WAVE));
-                    mfma_sources<T>(acc, lds, lds.tr + waveInBlock * F32_TR_FLOATS, hn_u, he_u, ws, j0, kLo, keLo, keHi, lane, pc);
+                    mfma_sources<T>(acc, lds, lds.tr + waveInBlock * F32_TR_FLOATS, hn_u, he_u, ws, j0, kLo, keLo, keHi, ring0, haveRing0, lane, pc);
                 }
             } else {
                 /* ------------- phase A */
