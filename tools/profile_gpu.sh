@@ -16,4 +16,6 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE
   timeout -s KILL 200 rocprofv3 --pmc $pass --output-format csv -d "$out/pmc_$name" -- python3 "$root/bench.py" $args --steps 16 --warmup 16 > "$out/bench_pmc_$name.json" 2> "$out/pmc_$name.err" || { echo "pmc pass $name failed"; tail -5 "$out/pmc_$name.err"; exit 1; }
   echo "pass $name done"
 done
+# matrix-core counters (fast mode): optional, a name this rocprofv3 does not know must not fail the run
+timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES --output-format csv -d "$out/pmc_MFMA" -- python3 "$root/bench.py" $args --steps 16 --warmup 16 > "$out/bench_pmc_MFMA.json" 2> "$out/pmc_MFMA.err" && echo "pass MFMA done" || { echo "pass MFMA not available"; rm -rf "$out/pmc_MFMA"; }
 find "$out" -name '*.csv' | head -40
