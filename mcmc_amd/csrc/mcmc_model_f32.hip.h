@@ -583,12 +583,28 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
                 }
 
             }
-            /* ------------- phase B: the T days of the block, in order */
+            /* ------------- phase B: the T days of the block, in order.  Its table rows 0..T-1: through the scalar
+             * cache in the packed form; in the MFMA form from the LDS image into VGPRs (wave-uniform address =
+             * broadcast read) -- 64 SGPRs of rows on top of the stream's bookkeeping made hipcc spill and restore
+             * ~20 SGPRs per day */
+            [[maybe_unused]] float8_t rowB[MFMA ? T : 1];
+            if constexpr (MFMA) {
+#pragma unroll
+                for (int q = 0; q < T; ++q) rowB[q] = *(const float8_t*)(lds.tabF + (F32_TAB_PAD + q) * 8);
+            }
+            auto row_pos = [&](int q) -> float8_t {
+                if constexpr (MFMA) return rowB[q];
+                else return smem_rowf8(RFpos, q);
+            };
+            auto row_neg = [&](int q) -> float4_t {
+                if constexpr (MFMA) return *(const float4_t*)(lds.tabN + (F32_TAB_PAD + q) * 4);
+                else return smem_rowf4(RFneg, q);
+            };
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const int i = j0 + t;
 #pragma unroll
-                for (int tt = t; tt < T; ++tt) pair_pos<T>(acc, tt, ncur, smem_rowf8(RFpos, tt - t));   /* covid.h:403-410 */
+                for (int tt = t; tt < T; ++tt) pair_pos<T>(acc, tt, ncur, row_pos(tt - t));   /* covid.h:403-410 */
                 /* hospital capacity (covid.h:413-429), decided in double */
                 const double overCapacity = (double)acc[P_SR][t].x * M.probICU - capv[t];
                 const double extraDeaths = M.probLethal * overCapacity;
@@ -599,7 +615,7 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
                     keLo = min(keLo, i);
                     keHi = max(keHi, i);
 #pragma unroll
-                    for (int tt = t; tt < T; ++tt) pair_neg<T>(acc, tt, e, smem_rowf4(RFneg, tt - t));
+                    for (int tt = t; tt < T; ++tt) pair_neg<T>(acc, tt, e, row_neg(tt - t));
                 }
                 /* tomorrow's new infections (covid.h:446-462), in double */
                 const double pcf = pcfv[t];
