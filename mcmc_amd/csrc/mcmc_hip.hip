@@ -557,7 +557,7 @@ int mcmc_hip_set_tables(mcmc_hip_ctx* c, const double* R, int32_t n_lag) try {
     /* fast-mode tables: per lag (MI HI INC MILD SER REC DEAD 0) and (-SFS -RFS 1-DFS 0), every
      * entry formed in double and rounded once; rows >= nLag stay zero.  One buffer: the
      * positive table first, the correction table behind it. */
-    const size_t rowsF = (size_t)c->size + 3 * MCMC_TF;
+    const size_t rowsF = (size_t)c->size + 3 * MCMC_TF + 8;     /* the MFMA form stages up to simDays + MCMC_TM + 7 of them */
     std::vector<float> rf(rowsF * 12, 0.0f);
     for (int d = 0; d < c->nLag; ++d) {
         float* rowp = rf.data() + (size_t)d * 8;

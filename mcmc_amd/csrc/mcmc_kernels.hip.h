@@ -211,9 +211,11 @@ struct LdsView {
     const double* sigma2;     /* [nData]  */
     const int* seg;           /* [simPad] */
     /* fast mode on the matrix cores only (stage_lds_f32, mcmc_model_f32.hip.h); null otherwise */
-    const float* tabF;        /* [F32_TAB_PAD + rowsL][8] float response table, F32_TAB_PAD rows of zeros in front */
-    const float* tabN;        /* [F32_TAB_PAD + rowsL][4] capacity-correction table (-SFS -RFS 1-DFS 0), padded alike */
-    float* tr;                /* [waves of the workgroup][64][F32_TR_ROW + F32_TR2_ROW] transposition buffers */
+    const float* tabF;        /* [F32_TAB_PAD + rowsL + F32_TAB_SLACK][7] float response table, pad rows of zeros in front */
+    const float* tabN;        /* [same rows][3] capacity-correction table (-SFS -RFS 1-DFS) */
+    const float* rowsB;       /* [MCMC_TM][8]: rows 0..MCMC_TM-1 of the response table for the sequential part */
+    const float* rowsNB;      /* [MCMC_TM][4]: ... of the correction table */
+    float* tr;                /* [waves of the workgroup][64][F32_TR_ROW] transposition buffers */
 };
 
 __host__ __device__ inline int lds_rows(const DevModel& M, bool derive, int T) {
@@ -250,38 +252,55 @@ __device__ inline LdsView stage_lds(const DevModel& M, double* lds, bool derive,
     __syncthreads();
     LdsView v;
     v.Rpos = rp; v.Rneg = rn; v.capacity = cap; v.deaths = dea; v.sigma2 = sg2; v.seg = seg;
-    v.tabF = nullptr; v.tabN = nullptr; v.tr = nullptr;
+    v.tabF = nullptr; v.tabN = nullptr; v.rowsB = nullptr; v.rowsNB = nullptr; v.tr = nullptr;
     return v;
 }
 
-/* LDS image of the fast mode on the matrix cores: no double tables (its sequential part takes rows 0..7
- * through the scalar cache), the per-day constants as above, the two float tables the MFMA B operands are
- * read from, and per wave a 64 x 68 and a 64 x 36 float transposition buffer.  Lags reach horizon + 7 (day j0 + 7 of the
- * last block against the wave's first day); sources all of whose lags are >= nLagRows are skipped in blocks
- * of 8 days, so no row above nLagRows + 13 is read either. */
-#define F32_TAB_PAD 2         /* the B operand of the pair after the last one is requested too: rows 0 and -1 */
-#define F32_TR_ROW 68          /* floats per chain of the 8 days x 8 curves buffer (64 used) */
-#define F32_TR2_ROW 36         /* ... of the 8 days x 4 corrections buffer (32 used) */
-#define F32_TR_FLOATS (MCMC_WAVE * (F32_TR_ROW + F32_TR2_ROW))
+/* LDS image of the fast mode on the matrix cores: no double tables, the per-day constants as above, the two
+ * float tables the MFMA B operands are read from -- SEVEN floats per lag (no pad column: a block of MCMC_TM = 9
+ * days x 7 curves fills 63 of the 64 MFMA columns) and three per lag for the corrections --, rows 0..MCMC_TM-1 of
+ * both once more in 16-byte aligned rows for the sequential part, and one 64 x F32_TR_ROW float transposition
+ * buffer per wave.  Lags reach horizon + MCMC_TM (last day of the last block against the first source day, one
+ * more for the pair alignment); sources all of whose lags are >= nLagRows are skipped in whole blocks, so no row
+ * above nLagRows + 2 MCMC_TM + 2 is read either. */
+#ifndef MCMC_TM
+#define MCMC_TM 9             /* days per block of the MFMA form */
+#endif
+#define F32_NC 7              /* floats per lag of the MFMA response table */
+#define F32_NE 3              /* ... of the correction table */
+#define F32_TAB_PAD 2         /* the B operand of the pair after the last one is requested too: rows -1 and -2 */
+#define F32_TAB_SLACK 2       /* the unused 64th column / lanes 27..31 of the correction tile read past the last row */
+#define F32_TR_ROW 76         /* floats per chain of the hand-over buffer: MCMC_TM days x 8 = 72 used */
+#define F32_TR_FLOATS (MCMC_WAVE * F32_TR_ROW)
+static_assert(MCMC_TM * F32_NC <= 64 && MCMC_TM * F32_NE <= 32 && MCMC_TM * 8 <= F32_TR_ROW, "block does not fit the MFMA tiles");
 __host__ __device__ inline int lds_rows_f32(const DevModel& M) {
-    const int a = M.simDays + 8, b = M.nLagRows + 16;
+    const int a = M.simDays + MCMC_TM + 3, b = M.nLagRows + 2 * MCMC_TM + 6;
     return a < b ? a : b;
 }
-__host__ __device__ inline size_t lds_bytes_f32(const DevModel& M) {
-    /* every part starts 16-byte aligned (the transposition buffers are read 16 bytes at a time) */
-    const size_t nd = ((size_t)M.simPad + 2 * (size_t)M.nData + 1) & ~(size_t)1, ni = ((size_t)M.simPad + 3) & ~(size_t)3;
-    return sizeof(double) * nd + sizeof(int) * ni +
-           sizeof(float) * ((size_t)(F32_TAB_PAD + lds_rows_f32(M)) * 12 + (size_t)MCMC_WAVES_PER_BLOCK * F32_TR_FLOATS) + 16;
+struct F32Image { size_t nd, ni, ntab, nrowsB, total; };      /* element counts of the parts, bytes in total */
+__host__ __device__ inline F32Image f32_image(const DevModel& M) {
+    F32Image I;
+    I.nd = ((size_t)M.simPad + 2 * (size_t)M.nData + 1) & ~(size_t)1;            /* doubles, 16-byte multiple */
+    I.ni = ((size_t)M.simPad + 3) & ~(size_t)3;                                   /* ints */
+    I.ntab = ((size_t)(F32_TAB_PAD + lds_rows_f32(M) + F32_TAB_SLACK) * (F32_NC + F32_NE) + 3) & ~(size_t)3;   /* floats */
+    I.nrowsB = (size_t)MCMC_TM * 12;                                               /* floats */
+    I.total = sizeof(double) * I.nd + sizeof(int) * I.ni +
+              sizeof(float) * (I.ntab + I.nrowsB + (size_t)MCMC_WAVES_PER_BLOCK * F32_TR_FLOATS) + 16;
+    return I;
 }
+__host__ __device__ inline size_t lds_bytes_f32(const DevModel& M) { return f32_image(M).total; }
 __device__ inline LdsView stage_lds_f32(const DevModel& M, double* lds) {
-    const int rows = lds_rows_f32(M);
+    const F32Image I = f32_image(M);
+    const int rowsAll = F32_TAB_PAD + lds_rows_f32(M) + F32_TAB_SLACK;
     double* cap = lds;
     double* dea = cap + M.simPad;
     double* sg2 = dea + M.nData;
-    int* seg = (int*)(lds + (((size_t)M.simPad + 2 * (size_t)M.nData + 1) & ~(size_t)1));
-    float* tf = (float*)(seg + (((size_t)M.simPad + 3) & ~(size_t)3));
-    float* tn = tf + (size_t)(F32_TAB_PAD + rows) * 8;
-    float* tr = tn + (size_t)(F32_TAB_PAD + rows) * 4;
+    int* seg = (int*)(lds + I.nd);
+    float* tf = (float*)(seg + I.ni);
+    float* tn = tf + (size_t)rowsAll * F32_NC;
+    float* rb = tf + I.ntab;
+    float* rnb = rb + (size_t)MCMC_TM * 8;
+    float* tr = rb + I.nrowsB;
     for (int i = threadIdx.x; i < M.simPad; i += blockDim.x) {
         cap[i] = M.capacity[i];
         seg[i] = M.seg[i];
@@ -290,14 +309,21 @@ __device__ inline LdsView stage_lds_f32(const DevModel& M, double* lds) {
         dea[i] = M.deaths[i];
         sg2[i] = M.sigma2[i];
     }
-    for (int i = threadIdx.x; i < (F32_TAB_PAD + rows) * 8; i += blockDim.x)
-        tf[i] = i >= F32_TAB_PAD * 8 ? M.RF[i - F32_TAB_PAD * 8] : 0.0f;
-    for (int i = threadIdx.x; i < (F32_TAB_PAD + rows) * 4; i += blockDim.x)
-        tn[i] = i >= F32_TAB_PAD * 4 ? M.RFn[i - F32_TAB_PAD * 4] : 0.0f;
+    /* the global float tables have 8 / 4 floats per lag and zeros from nLagRows on (mcmc_hip_set_tables) */
+    for (int i = threadIdx.x; i < rowsAll * F32_NC; i += blockDim.x) {
+        const int r = i / F32_NC - F32_TAB_PAD, c = i % F32_NC;
+        tf[i] = r >= 0 ? M.RF[r * 8 + c] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < rowsAll * F32_NE; i += blockDim.x) {
+        const int r = i / F32_NE - F32_TAB_PAD, c = i % F32_NE;
+        tn[i] = r >= 0 ? M.RFn[r * 4 + c] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < MCMC_TM * 8; i += blockDim.x) rb[i] = M.RF[i];
+    for (int i = threadIdx.x; i < MCMC_TM * 4; i += blockDim.x) rnb[i] = M.RFn[i];
     __syncthreads();
     LdsView v;
     v.Rpos = nullptr; v.Rneg = nullptr; v.capacity = cap; v.deaths = dea; v.sigma2 = sg2; v.seg = seg;
-    v.tabF = tf; v.tabN = tn; v.tr = tr;
+    v.tabF = tf; v.tabN = tn; v.rowsB = rb; v.rowsNB = rnb; v.tr = tr;
     return v;
 }
 /* PREC: 0 = double (the reference's arithmetic), 1 = fast mode with packed FP32 multiply-adds, 2 = fast mode
@@ -1391,7 +1417,7 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_kernel(DevModel M, ChainState S, int n
             const bool behChanged = propose(M, rnd, xc_u, xp_u, lane, stepsize, lp, llpNew);
             pc.stamp(PH_PROPOSE);
             double llm;
-            if constexpr (PREC != 0) llm = eval_model_f32<MCMC_TF, PREC == 2>(M, lds, B, lp, lane, work, pc);   /* fast mode */
+            if constexpr (PREC != 0) llm = eval_model_f32<(PREC == 2 ? MCMC_TM : MCMC_TF), PREC == 2>(M, lds, B, lp, lane, work, pc);   /* fast mode */
             else llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, work, pc);
             double llp = 0.0;
             double delta = 0;                                           /* mcmc.h:604-606 */
@@ -1544,7 +1570,7 @@ __global__ MCMC_KERNEL_ATTRS void eval_kernel(DevModel M, ChainState S, const do
         LaneScalars lp;
         load_lane_scalars(M, B.x_u, lane, lp);
         double llm;
-        if constexpr (PREC != 0) llm = eval_model_f32<MCMC_TF, PREC == 2>(M, lds, B, lp, lane, work, pc);
+        if constexpr (PREC != 0) llm = eval_model_f32<(PREC == 2 ? MCMC_TM : MCMC_TF), PREC == 2>(M, lds, B, lp, lane, work, pc);
         else llm = eval_model<T, FUSE, false>(M, lds, B, lp, lane, work, pc);
         const double llp = M.hasPrior ? eval_prior(M, B.x_u, lane) : 0.0;
         llOut[((size_t)tile * 2) * MCMC_WAVE + lane] = llm;

@@ -210,10 +210,9 @@ __device__ __forceinline__ void mfma_ring_load(float (&ra)[RING][2], const float
     for (int u = 0; u < RING; ++u) ld_pair(ra[u], hp + u * 128);
 }
 /* `ra`: the first RING pairs (mfma_ring_load, possibly issued long before, or a copy kept from an earlier block) */
-template <int RING, int NT>
+template <int RING, int NT, int BSTEP>
 __device__ __forceinline__ void mfma_stream(float16v_t (&C)[2][NT], float (&ra)[RING][2], const float* hp, const float* tab,
                                             int li, int nPairs) {
-    constexpr int BSTEP = NT == 2 ? 16 : 8;
     float bv[NT];
 #pragma unroll
     for (int q = 0; q < NT; ++q) bv[q] = tab[li + 32 * q];
@@ -265,17 +264,29 @@ __device__ __forceinline__ void mfma_stream(float16v_t (&C)[2][NT], float (&ra)[
     }
 }
 
-/* All sources before the block (days kLo .. j0-1; ws, kLo and j0 are multiples of 8) for the block's 8 days,
+/* All sources before the block (days kLo .. j0-1; ws, kLo and j0 are multiples of T) for the block's T days,
  * the capacity corrections of the source days [eLo, eHi] among them, and the hand-over to chain-per-lane.
- * The corrections touch three curves only, so their B tile is 8 days x (-SFS, -RFS, 1-DFS, 0): one N tile
- * covers the whole block and a pair costs two MFMAs, not four. */
+ * Pairs of source days are (2p, 2p+1) in ABSOLUTE days.  With T = 9 a block may start on an odd day: the pair
+ * that straddles the start is applied with the A value of its second day forced to zero (that day belongs to
+ * the block), and a pair below kLo's parity reaches one day further back, whose contribution is an exact zero
+ * (zeroed history below the first day, or lags >= nLagRows: rows of zeros).  The corrections touch three
+ * curves only: their B tile is T days x (-SFS, -RFS, 1-DFS) in one 32-column tile, two MFMAs per pair. */
 #define F32_RING 16           /* pairs of history values in flight in the main stream */
 #define F32_RING_E 8          /* ... in the corrections' stream */
+template <int NT>
+__device__ __forceinline__ void mfma_once(float16v_t (&C)[2][NT], float a0, float a1, const float* tab, int li) {
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        const float bq = tab[li + 32 * q];
+        C[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq, C[0][q], 0, 0, 0);
+        C[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq, C[1][q], 0, 0, 0);
+    }
+}
 template <int T>
 __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsView& lds, float* tr, const float* hn_u,
                                              const float* he_u, int ws, int j0, int kLo, int eLo, int eHi,
                                              float (&ring0)[F32_RING][2], bool& haveRing0, unsigned lane, PhaseClock& pc) {
-    static_assert(T == 8, "one block = 2 x 32 MFMA columns = 8 days x 8 curves");
+    static_assert(T * F32_NC <= 64 && T * F32_NE <= 32 && T * 8 <= F32_TR_ROW, "block does not fit the MFMA tiles");
     constexpr int HOFF = 2 * T;
     const int half = (int)(lane >> 5), n = (int)(lane & 31);
     float16v_t C[2][2];
@@ -285,63 +296,76 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) C[a][b][i] = 0.0f;
-    /* pairs are aligned to even days; the corrections' are those touching [eLo, eHi], not before kLo, not into
-     * the block.  Their first ring is requested before the main stream, which hides the round trip. */
-    const int pLo = (max(eLo, kLo) - ws) / 2, pHi = min((eHi - ws) / 2, (j0 - ws) / 2 - 1);
+    const int kE0 = kLo & ~1;                           /* first day of the first pair */
+    const int nFull = (j0 - kE0) >> 1;                  /* pairs entirely before the block */
+    const bool straddle = ((j0 - kE0) & 1) != 0;        /* pair (j0-1, j0): its second day is the block's first */
+    /* corrections: the pairs touching [max(eLo, kLo), eHi]; whole ones first, then the straddling one */
+    const int pLo = max(eLo, kLo) >> 1, pHi = min(eHi >> 1, (j0 >> 1) - 1);
     const bool withE = eHi >= eLo && pHi >= pLo;
-    const int kE = withE ? ws + 2 * pLo : ws;
+    const bool tailE = straddle && eHi >= eLo && j0 - 1 <= eHi && j0 - 1 >= max(eLo, kLo);
+    const int kE = withE ? 2 * pLo : kE0;
     const float* hpe = he_u + (kE + half + HOFF) * MCMC_WAVE + 2 * n;
     float re[F32_RING_E][2];
-    if (withE) mfma_ring_load<F32_RING_E>(re, hpe);
+    if (withE) mfma_ring_load<F32_RING_E>(re, hpe);     /* requested before the main stream: the round trip hides there */
     {
-        /* Without lag skipping every block of a pass starts its stream with the SAME 32 history rows
-         * (ws .. ws+31): once they all lie before the block a copy stays in registers and the later blocks
-         * start without a memory round trip. */
-        const float* hp = hn_u + (kLo + half + HOFF) * MCMC_WAVE + 2 * n;
-        const int li = (j0 - kLo - half + F32_TAB_PAD) * 8 + n;
-        float ra[F32_RING][2];
-        if (haveRing0 && kLo == ws) {
+        /* Without lag skipping every block of a pass starts its stream with the SAME 32 history rows: once they
+         * all lie before the block a copy stays in registers and the later blocks start without a memory round
+         * trip. */
+        const float* hp = hn_u + (kE0 + half + HOFF) * MCMC_WAVE + 2 * n;
+        const int li = (j0 - kE0 - half + F32_TAB_PAD) * F32_NC + n;
+        if (nFull > 0) {
+            float ra[F32_RING][2];
+            if (haveRing0 && kLo == ws) {
 #pragma unroll
-            for (int u = 0; u < F32_RING; ++u) { ra[u][0] = ring0[u][0]; ra[u][1] = ring0[u][1]; }
-        } else {
-            mfma_ring_load<F32_RING>(ra, hp);
-            if (kLo == ws && j0 - ws >= 2 * F32_RING) {
+                for (int u = 0; u < F32_RING; ++u) { ra[u][0] = ring0[u][0]; ra[u][1] = ring0[u][1]; }
+            } else {
+                mfma_ring_load<F32_RING>(ra, hp);
+                if (kLo == ws && nFull >= F32_RING) {
 #pragma unroll
-                for (int u = 0; u < F32_RING; ++u) { ring0[u][0] = ra[u][0]; ring0[u][1] = ra[u][1]; }
-                haveRing0 = true;
+                    for (int u = 0; u < F32_RING; ++u) { ring0[u][0] = ra[u][0]; ring0[u][1] = ra[u][1]; }
+                    haveRing0 = true;
+                }
             }
+            mfma_stream<F32_RING, 2, 2 * F32_NC>(C, ra, hp, lds.tabF, li, nFull);
         }
-        mfma_stream<F32_RING, 2>(C, ra, hp, lds.tabF, li, (j0 - kLo) / 2);
+        if (straddle) {
+            float a[2];
+            ld_pair(a, hn_u + (j0 - 1 + HOFF) * MCMC_WAVE + 2 * n);
+            mfma_once<2>(C, half ? 0.0f : a[0], half ? 0.0f : a[1], lds.tabF, (1 - half + F32_TAB_PAD) * F32_NC + n);
+        }
     }
     pc.stamp(PH_CHUNKS);
-    float* tr2 = tr + MCMC_WAVE * F32_TR_ROW;           /* [64][F32_TR2_ROW]: the corrections' 8 days x 4 */
-    if (withE) {
-        float16v_t Ce[2][1];
+    float16v_t Ce[2][1];
+    if (withE || tailE) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int i = 0; i < 16; ++i) Ce[a][0][i] = 0.0f;
-        const int li = (j0 - kE - half + F32_TAB_PAD) * 4 + n;
-        mfma_stream<F32_RING_E, 1>(Ce, re, hpe, lds.tabN, li, pHi - pLo + 1);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) tr2[(2 * (8 * (v / 4) + 4 * half + (v % 4)) + mt) * F32_TR2_ROW + n] = Ce[mt][0][v];
+        if (withE) mfma_stream<F32_RING_E, 1, 2 * F32_NE>(Ce, re, hpe, lds.tabN, (j0 - kE - half + F32_TAB_PAD) * F32_NE + n, pHi - pLo + 1);
+        if (tailE) {
+            float a[2];
+            ld_pair(a, he_u + (j0 - 1 + HOFF) * MCMC_WAVE + 2 * n);
+            mfma_once<1>(Ce, half ? 0.0f : a[0], half ? 0.0f : a[1], lds.tabN, (1 - half + F32_TAB_PAD) * F32_NE + n);
+        }
     }
     pc.stamp(PH_CHUNKS_E);
-    /* MFMA layout -> chain per lane: element v of tile (mt, nt) is chain 2 (8 (v/4) + 4 half + v%4) + mt,
-     * column 32 nt + n (= day 4 nt + n/8, curve n%8) */
+    /* MFMA layout -> chain per lane through the wave's LDS buffer: element v of tile (mt, nt) is chain
+     * 2 (8 (v/4) + 4 half + v%4) + mt, column 32 nt + n = (day, curve) 7 day + curve; a chain's row holds 8
+     * floats per day, so it comes back as two 16-byte reads per day (rows of 76 floats: lanes 8 apart share a
+     * bank group, which a 16-byte read of 64 lanes needs eight passes for anyway) */
+    const int col1 = 32 + n;
+    const int off0 = (n / F32_NC) * 8 + n % F32_NC, off1 = (col1 / F32_NC) * 8 + col1 % F32_NC;
+    const bool ok0 = n < T * F32_NC, ok1 = col1 < T * F32_NC;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int v = 0; v < 16; ++v)
-                tr[(2 * (8 * (v / 4) + 4 * half + (v % 4)) + mt) * F32_TR_ROW + 32 * nt + n] = C[mt][nt][v];
+        for (int v = 0; v < 16; ++v) {
+            float* row = tr + (2 * (8 * (v / 4) + 4 * half + (v % 4)) + mt) * F32_TR_ROW;
+            if (ok0) row[off0] = C[mt][0][v];
+            if (ok1) row[off1] = C[mt][1][v];
+        }
     __builtin_amdgcn_s_waitcnt(0xc07f);                 /* lgkmcnt(0): the wave's own LDS writes have landed */
     __builtin_amdgcn_wave_barrier();
-    /* rows of 68 / 36 floats: 16-byte aligned, so a day's eight sums come back as two 16-byte reads (lanes
-     * 8 apart share a bank group, which a 16-byte read of 64 lanes needs eight passes for anyway) */
     const float4_t* mine = (const float4_t*)(tr + lane * F32_TR_ROW);
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -349,19 +373,30 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
         acc[P_INF][t] = float2_t{lo[0], lo[1]};
         acc[P_IM][t] = float2_t{lo[2], lo[3]};
         acc[P_SR][t] = float2_t{hi[0], hi[1]};
-        acc[P_D][t] = float2_t{hi[2], hi[3]};
+        acc[P_D][t] = float2_t{hi[2], 0.0f};
     }
-    if (withE) {
-        const float4_t* mine2 = (const float4_t*)(tr2 + lane * F32_TR2_ROW);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                 /* read back before the buffer is written again */
+    __builtin_amdgcn_wave_barrier();
+    if (withE || tailE) {
+        /* the corrections' tile through the same buffer: column n = (day, curve) 3 day + curve, 4 floats per day */
+        const int offE = (n / F32_NE) * 4 + n % F32_NE;
+        const bool okE = n < T * F32_NE;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                if (okE) tr[(2 * (8 * (v / 4) + 4 * half + (v % 4)) + mt) * F32_TR_ROW + offE] = Ce[mt][0][v];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const float4_t e4 = mine2[t];
+            const float4_t e4 = mine[t];
             acc[P_SR][t] += float2_t{e4[0], e4[1]};
             acc[P_D][t].x += e4[2];
         }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);                 /* read back before the next block overwrites the buffer */
-    __builtin_amdgcn_wave_barrier();
     pc.stamp(PH_TAIL);
 }
 
@@ -418,10 +453,10 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
         int ws = wave_min_i32(s);
         ws = min(ws, md);
         /* On the matrix cores a chain's sums must not depend on who shares its wave: an MFMA adds the two
-         * products of a source-day pair in one step (not as two chained multiply-adds), so pairs and 8-day
-         * blocks are aligned to ABSOLUTE days, not to the wave's first day.  The up to 7 days before ws are
+         * products of a source-day pair in one step (not as two chained multiply-adds), so pairs and T-day
+         * blocks are aligned to ABSOLUTE days, not to the wave's first day.  The up to T-1 days before ws are
          * "not started" days for every lane (zeros, handled below like any day i < s). */
-        if constexpr (MFMA) ws &= ~(T - 1);
+        if constexpr (MFMA) ws -= ws % T;
         int keLo = 0x7fffffff, keHi = -1;
 
         float ncur = (s == ws) ? 1.0f : 0.0f;                       /* patient zero, covid.h:339 */
@@ -447,7 +482,7 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
         }
         pc.stamp(PH_SETUP);
         double* ds_u = B.d1s_u + (shift == 1 ? 0 : M.nData * MCMC_WAVE);
-        [[maybe_unused]] float ring0[MFMA ? F32_RING : 1][2];       /* mfma_sources: the stream's first history rows */
+        [[maybe_unused]] float ring0[MFMA ? 16 : 1][2];       /* mfma_sources: the stream's first history rows */
         [[maybe_unused]] bool haveRing0 = false;
 
 #pragma unroll 1
@@ -475,11 +510,11 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
             if constexpr (MFMA) {
                 /* ------------- phase A on the matrix cores: every source day before the block */
                 int kLo = ws;                                        /* sources whose lags are all >= nLagRows: skipped */
-                if (j0 - M.nLagRows + 1 - ws > 0) kLo += (j0 - M.nLagRows + 1 - ws) / 8 * 8;
+                if (j0 - M.nLagRows + 1 - ws > 0) kLo += (j0 - M.nLagRows + 1 - ws) / T * T;
                 F32_ROWS(F32K_DAY_CONST, j0, j0 + T - 1, M.simPad);
                 F32_ROWS(F32K_HIST_DAYS, j0 + HOFF, j0 + T + HOFF, histF);
-                F32_ROWS(F32K_HIST_REFILL, kLo + HOFF, j0 + 2 * 16 + 1 + HOFF, histF);   /* the A ring reads 16 pairs ahead */
-                F32_ROWS(F32K_TABLE_FIRST, 0, j0 - kLo + T - 1, lds_rows_f32(M));
+                F32_ROWS(F32K_HIST_REFILL, kLo - 1 + HOFF, j0 + 2 * 16 + 1 + HOFF, histF);   /* the A ring reads 16 pairs ahead */
+                F32_ROWS(F32K_TABLE_FIRST, 0, j0 - kLo + 1 + T + 1, lds_rows_f32(M) + F32_TAB_SLACK);
                 request_block_inputs();
                 if (j0 > kLo) {
                     const int waveInBlock = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / MCMC_WAVE));
@@ -590,14 +625,14 @@ __device__ __forceinline__ double eval_model_f32(const DevModel& M, const LdsVie
             [[maybe_unused]] float8_t rowB[MFMA ? T : 1];
             if constexpr (MFMA) {
 #pragma unroll
-                for (int q = 0; q < T; ++q) rowB[q] = *(const float8_t*)(lds.tabF + (F32_TAB_PAD + q) * 8);
+                for (int q = 0; q < T; ++q) rowB[q] = *(const float8_t*)(lds.rowsB + q * 8);
             }
             auto row_pos = [&](int q) -> float8_t {
                 if constexpr (MFMA) return rowB[q];
                 else return smem_rowf8(RFpos, q);
             };
             auto row_neg = [&](int q) -> float4_t {
-                if constexpr (MFMA) return *(const float4_t*)(lds.tabN + (F32_TAB_PAD + q) * 4);
+                if constexpr (MFMA) return *(const float4_t*)(lds.rowsNB + q * 4);
                 else return smem_rowf4(RFneg, q);
             };
 #pragma unroll
