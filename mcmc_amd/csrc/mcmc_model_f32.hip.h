@@ -286,7 +286,7 @@ template <int T>
 __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsView& lds, float* tr, const float* hn_u,
                                              const float* he_u, int ws, int j0, int kLo, int eLo, int eHi,
                                              float (&ring0)[F32_RING][2], bool& haveRing0, unsigned lane, PhaseClock& pc) {
-    static_assert(T * F32_NC <= 64 && T * F32_NE <= 32 && T * 8 <= F32_TR_ROW, "block does not fit the MFMA tiles");
+    static_assert(T * F32_NC <= 64 && T * F32_NE <= 32 && T * 8 + 3 <= F32_TR_ROW, "block does not fit the MFMA tiles");
     constexpr int HOFF = 2 * T;
     const int half = (int)(lane >> 5), n = (int)(lane & 31);
     float16v_t C[2][2];
@@ -354,15 +354,16 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
      * floats per day, so it comes back as two 16-byte reads per day (rows of 76 floats: lanes 8 apart share a
      * bank group, which a 16-byte read of 64 lanes needs eight passes for anyway) */
     const int col1 = 32 + n;
-    const int off0 = (n / F32_NC) * 8 + n % F32_NC, off1 = (col1 / F32_NC) * 8 + col1 % F32_NC;
-    const bool ok0 = n < T * F32_NC, ok1 = col1 < T * F32_NC;
+    /* columns past the block's last curve go to the row's unused tail instead of being predicated off */
+    const int off0 = n < T * F32_NC ? (n / F32_NC) * 8 + n % F32_NC : T * 8;
+    const int off1 = col1 < T * F32_NC ? (col1 / F32_NC) * 8 + col1 % F32_NC : T * 8 + 1;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             float* row = tr + (2 * (8 * (v / 4) + 4 * half + (v % 4)) + mt) * F32_TR_ROW;
-            if (ok0) row[off0] = C[mt][0][v];
-            if (ok1) row[off1] = C[mt][1][v];
+            row[off0] = C[mt][0][v];
+            row[off1] = C[mt][1][v];
         }
     __builtin_amdgcn_s_waitcnt(0xc07f);                 /* lgkmcnt(0): the wave's own LDS writes have landed */
     __builtin_amdgcn_wave_barrier();
@@ -379,13 +380,12 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
     __builtin_amdgcn_wave_barrier();
     if (withE || tailE) {
         /* the corrections' tile through the same buffer: column n = (day, curve) 3 day + curve, 4 floats per day */
-        const int offE = (n / F32_NE) * 4 + n % F32_NE;
-        const bool okE = n < T * F32_NE;
+        const int offE = n < T * F32_NE ? (n / F32_NE) * 4 + n % F32_NE : T * 8 + 2;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int v = 0; v < 16; ++v)
-                if (okE) tr[(2 * (8 * (v / 4) + 4 * half + (v % 4)) + mt) * F32_TR_ROW + offE] = Ce[mt][0][v];
+                tr[(2 * (8 * (v / 4) + 4 * half + (v % 4)) + mt) * F32_TR_ROW + offE] = Ce[mt][0][v];
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
