@@ -25,17 +25,18 @@
  *    as well.
  *
  * MFMA = true (the default fast mode, MCMC_HIP_PRECISION_F32_MODEL) moves the whole contraction over the source
- * days BEFORE a block onto the FP32 matrix cores: for a tile of 64 chains and the block's 8 days,
- *     C[chain][(t, c)] = sum_k hist[k][chain] * table[j0 + t - k][c]
- * is a (64 x K) x (K x 64) product whose B operand is Toeplitz in (k, t).  v_mfma_f32_32x32x2_f32 takes
- * M = 32 chains, N = 32 = 4 days x 8 curves and K = 2 source days: lane l supplies A = hist[k0 + l/32][l%32]
- * (one coalesced dword of the float history) and B = table[(j0 - k0 - l/32) * 8 + l%32], 32 consecutive floats
- * of the LDS image because (day, curve) -> 8 * day + curve.  Four MFMAs (2 chain halves x 2 day halves) do the
- * 8 192 multiply-adds of two source days; the capacity corrections are the same product with the e-history as
- * A and the table (0 0 0 0 -SFS -RFS 1-DFS 0) as B over the source days that carry any.  At the end of the
- * block the 64 sums of a chain go from the MFMA layout to chain-per-lane through an LDS buffer of the wave's
- * own (rows of 65 floats), and the sequential part runs as before.  Summation order differs from the packed
- * form (pairs of source days, then the in-block sources); both are FP32 and held to the same statistical bar.
+ * days BEFORE a block onto the FP32 matrix cores: for a tile of 64 chains and the block's T = MCMC_TM = 9 days,
+ *     C[chain][7 t + c] = sum_k hist[k][chain] * table7[(j0 + t - k) * 7 + c]
+ * is a (64 x K) x (K x 63) product whose B operand is Toeplitz in (k, t).  v_mfma_f32_32x32x2_f32 takes
+ * M = 32 chains (the even or the odd ones of the wave), N = 32 columns and K = 2 source days: lane l supplies
+ * A = hist[k0 + l/32][2 (l%32) + tile] (both chain tiles' values in one coalesced 8-byte load) and
+ * B = table7[(j0 - k0 - l/32) * 7 + 32 q + l%32] for column tile q -- consecutive floats of the LDS image, which
+ * has 7 floats per lag and no pad column, so 9 days x 7 curves fill 63 of the 64 columns.  Four MFMAs do the
+ * multiply-adds of two source days; the capacity corrections are the same product with the e-history as A and
+ * the table (-SFS -RFS 1-DFS), 3 floats per lag, as B: 27 of 32 columns, two MFMAs per pair.  At the end of the
+ * block the sums of a chain go from the MFMA layout to chain-per-lane through an LDS buffer of the wave's own,
+ * and the sequential part runs as before.  Summation order differs from the packed form (pairs of absolute
+ * source days, then the in-block sources); both are FP32 and held to the same statistical bar.
  */
 #pragma once
 
