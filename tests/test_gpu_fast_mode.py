@@ -94,6 +94,27 @@ def test_fast_mode_is_deterministic_and_independent_of_the_batch(R11, R10, fast)
 
 
 @pytest.mark.parametrize("fast", FAST)
+def test_fast_mode_batch_independence_on_a_long_horizon(R11, R10, fast):
+    """560 simulated days: lags run past the 500-row response table, so whole blocks of early source days are
+    skipped and (matrix-core form) the first source-day pair can start on an odd day.  A chain's bits still
+    must not depend on the batch: alone, permuted, or next to chains that start weeks earlier or later."""
+    cfg = make_cfg(520, R11, contract=1, cap0=3.0, cap_incr_rate=0.5, initial_beta_mild=1.5, initial_beta_high=4.0)
+    xs = perturbed(cfg, 70, 0.05)
+    xs[::4, -1] = 3.25                               # first days spread over the whole admissible range
+    xs[1::4, -1] = 38.5
+    xs[::3, -3] *= 0.3                               # lanes with and without capacity corrections
+    s = H.CovidSampler(cfg, R10, precision=fast)
+    a = s.eval(xs)
+    assert np.all(np.isfinite(a[:, 0]))
+    perm = np.random.default_rng(5).permutation(70)
+    assert np.array_equal(a[perm], s.eval(xs[perm]))
+    for i in (0, 1, 2, 5, 69):
+        assert np.array_equal(a[i:i + 1], s.eval(xs[i:i + 1])), i
+    assert np.array_equal(a[64:], s.eval(xs[64:]))
+    s.close()
+
+
+@pytest.mark.parametrize("fast", FAST)
 def test_fast_mode_full_size_properties(R11, R10, fast):
     """BASELINE configs[2] shape (365 days, dim 358) at 16384 chains in the fast mode: a scattered
     subset run alone ends on the same bits, a repeat run is bit-identical, the log-likelihoods of the
