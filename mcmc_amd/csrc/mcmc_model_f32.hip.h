@@ -308,6 +308,10 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
     const float* hpe = he_u + (kE + half + HOFF) * MCMC_WAVE + 2 * n;
     float re[F32_RING_E][2];
     if (withE) mfma_ring_load<F32_RING_E>(re, hpe);     /* requested before the main stream: the round trip hides there */
+    /* ... and so are the values of the straddling pair's first day (only the lanes of the lower half use them) */
+    float as[2] = {0.0f, 0.0f}, aes[2] = {0.0f, 0.0f};
+    if (straddle) ld_pair(as, hn_u + (j0 - 1 + HOFF) * MCMC_WAVE + 2 * n);
+    if (tailE) ld_pair(aes, he_u + (j0 - 1 + HOFF) * MCMC_WAVE + 2 * n);
     {
         /* Without lag skipping every block of a pass starts its stream with the SAME 32 history rows: once they
          * all lie before the block a copy stays in registers and the later blocks start without a memory round
@@ -329,11 +333,7 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
             }
             mfma_stream<F32_RING, 2, 2 * F32_NC>(C, ra, hp, lds.tabF, li, nFull);
         }
-        if (straddle) {
-            float a[2];
-            ld_pair(a, hn_u + (j0 - 1 + HOFF) * MCMC_WAVE + 2 * n);
-            mfma_once<2>(C, half ? 0.0f : a[0], half ? 0.0f : a[1], lds.tabF, (1 - half + F32_TAB_PAD) * F32_NC + n);
-        }
+        if (straddle) mfma_once<2>(C, half ? 0.0f : as[0], half ? 0.0f : as[1], lds.tabF, (1 - half + F32_TAB_PAD) * F32_NC + n);
     }
     pc.stamp(PH_CHUNKS);
     float16v_t Ce[2][1];
@@ -343,11 +343,7 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
 #pragma unroll
             for (int i = 0; i < 16; ++i) Ce[a][0][i] = 0.0f;
         if (withE) mfma_stream<F32_RING_E, 1, 2 * F32_NE>(Ce, re, hpe, lds.tabN, (j0 - kE - half + F32_TAB_PAD) * F32_NE + n, pHi - pLo + 1);
-        if (tailE) {
-            float a[2];
-            ld_pair(a, he_u + (j0 - 1 + HOFF) * MCMC_WAVE + 2 * n);
-            mfma_once<1>(Ce, half ? 0.0f : a[0], half ? 0.0f : a[1], lds.tabN, (1 - half + F32_TAB_PAD) * F32_NE + n);
-        }
+        if (tailE) mfma_once<1>(Ce, half ? 0.0f : aes[0], half ? 0.0f : aes[1], lds.tabN, (1 - half + F32_TAB_PAD) * F32_NE + n);
     }
     pc.stamp(PH_CHUNKS_E);
     /* MFMA layout -> chain per lane through the wave's LDS buffer: element v of tile (mt, nt) is chain
