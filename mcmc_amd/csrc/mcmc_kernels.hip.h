@@ -797,35 +797,44 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                 if (cHi < cLo) { cLo = bRun; cHi = bRun - 1; }
             }
             const double* ek0 = ebase + cLo * T * MCMC_WAVE;
-#pragma unroll 1
-            for (int seg = 0; seg < 3; ++seg) {
-                int nch = (seg == 0) ? cLo - c0r : (seg == 1) ? cHi - cLo + 1 : bRun - 1 - cHi;
-                pc.count(seg == 1 ? PH_NCHUNK_E : PH_NCHUNK, nch);
-                /* The lane index the lag loops address with is re-defined here, as an opaque
-                 * copy.  Otherwise the compiler may reload its (spilled) 64-bit lane offset
-                 * just ahead of a loop; a load still pending at the loop header makes the
-                 * wait-count pass put a full vmcnt(0) INSIDE the loop, which drains the
-                 * window prefetch every iteration. */
+            /* The lane index the lag loops address with is re-defined ahead of each run, as an opaque
+             * copy.  Otherwise the compiler may reload its (spilled) 64-bit lane offset just ahead of a
+             * loop; a load still pending at the loop header makes the wait-count pass put a full vmcnt(0)
+             * INSIDE the loop, which drains the window prefetch every iteration.
+             * The three runs are three pieces of straight-line code, not one loop over a run index: as a
+             * loop, the 56 accumulators and both windows went through a register-to-register copy at
+             * every run's entry (~230 instructions, up to three times per block). */
+            auto run_plain = [&](int nch) {
+                pc.count(PH_NCHUNK, nch);
                 unsigned laneL = lane;
 #if MCMC_LANE_LAUNDER
                 asm volatile("" : "+v"(laneL));
 #endif
-                if (seg != 1) {
 #pragma unroll 1
-                    for (; nch >= 2; nch -= 2) {
-                        lag_chunk<T, FUSE>(acc, WA, WB, r, MCMC_TAB(lds, M), Lc, hnx, laneL);
-                        lag_chunk<T, FUSE>(acc, WB, WA, r, MCMC_TAB(lds, M), Lc - T, hnx + T * MCMC_WAVE, laneL);
-                        hnx += 2 * T * MCMC_WAVE;
-                        Lc -= 2 * T;
-                    }
-                    if (nch > 0) {
-                        lag_chunk<T, FUSE>(acc, WA, WB, r, MCMC_TAB(lds, M), Lc, hnx, laneL);
+                for (; nch >= 2; nch -= 2) {
+                    lag_chunk<T, FUSE>(acc, WA, WB, r, MCMC_TAB(lds, M), Lc, hnx, laneL);
+                    lag_chunk<T, FUSE>(acc, WB, WA, r, MCMC_TAB(lds, M), Lc - T, hnx + T * MCMC_WAVE, laneL);
+                    hnx += 2 * T * MCMC_WAVE;
+                    Lc -= 2 * T;
+                }
+                if (nch > 0) {
+                    lag_chunk<T, FUSE>(acc, WA, WB, r, MCMC_TAB(lds, M), Lc, hnx, laneL);
 #pragma unroll
-                        for (int q = 0; q < T; ++q) { const double tmp = WA[q]; WA[q] = WB[q]; WB[q] = tmp; }
-                        hnx += T * MCMC_WAVE;
-                        Lc -= T;
-                    }
-                } else if (nch > 0) {
+                    for (int q = 0; q < T; ++q) { const double tmp = WA[q]; WA[q] = WB[q]; WB[q] = tmp; }
+                    hnx += T * MCMC_WAVE;
+                    Lc -= T;
+                }
+                pc.stamp(PH_CHUNKS);
+            };
+            run_plain(cLo - c0r);
+            {
+                int nch = cHi - cLo + 1;
+                pc.count(PH_NCHUNK_E, nch);
+                unsigned laneL = lane;
+#if MCMC_LANE_LAUNDER
+                asm volatile("" : "+v"(laneL));
+#endif
+                if (nch > 0) {
                     /* e-window of the run's first chunk (one exposed round trip per block),
                      * refilled two chunks ahead from then on */
                     double EA[T], EB[T];
@@ -859,8 +868,9 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                         Lc -= T;
                     }
                 }
-                pc.stamp(seg == 1 ? PH_CHUNKS_E : PH_CHUNKS);
+                pc.stamp(PH_CHUNKS_E);
             }
+            run_plain(bRun - 1 - cHi);
             /* what phase B needs from memory is requested before the tail's 7*T*(T-1)/2
              * multiply-adds: behaviour values and piecewise factors of the block's days.
              * Rows 0..T-1 across the lanes, for the tail and phase B of this block (re-read per
