@@ -1,0 +1,57 @@
+"""bench.py's output contract, checked on small workloads: ONE JSON line from rank 0 with the driver's keys, the
+`roofline` and `cpu_baseline` objects of the measurement section, the strict / fast-mode / ESS legs, and the
+self-launched two-rank path (two ranks rehearsed on one card over gloo).  Not a performance test."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, timeout=600):
+    env = dict(os.environ)
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # exactly one JSON line (gloo itself may print a connection notice on stdout in the rehearsal mode)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_whole_contract():
+    d = _bench("--chains-per-gpu", "4096", "--steps", "16", "--warmup", "16", "--adjust", "2",
+               "--ess-chains", "512", "--ess-steps", "200")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 16 and d["warmup"] == 16 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and d["config"]["chains_per_gpu"] == 4096
+    assert d["value"] > 0 and abs(d["value"] - 4096 * 16 / (d["ms_per_step"] * 16e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_per_launch", "executed"):
+        assert k in rf, k
+    assert rf["unit"] == "TFLOP/s" and rf["peak"] == 78.6 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert 0 < rf["executed"]["frac"] < rf["frac"] < 1            # executed work is a subset of the algorithmic count
+    assert rf["traffic"] is None or "from_profile" in rf["traffic_source"]
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample", "faithful"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > cb["faithful"]["value"] > 0
+    assert d["strict"]["fp_contract"] == "strict" and 0 < d["strict"]["value"] < d["value"]
+    assert d["fp32_fast_mode"]["peak"] == 157.3 and d["fp32_fast_mode"]["value"] > 0
+    assert "converged" in d["ess"] and (d["ess"]["converged"] or "ess_per_s" not in d["ess"])
+
+
+def test_gpus_flag_launches_its_ranks():
+    d = _bench("--gpus", "2", "--backend", "gloo", "--device", "0", "--chains-per-gpu", "2048", "--steps", "16",
+               "--warmup", "16", "--adjust", "2", "--no-cpu-baseline", "--ess-chains", "0")
+    assert d["n_gpus"] == 2 and d["diagnostics"]["ranks"] == 2 and d["diagnostics"]["chains"] == 4096
+    assert d["config"]["parallelism"].endswith("x2") and "gloo" in d["diagnostics"]["how"]
+    assert d["value"] > 0 and "cpu_baseline" not in d
