@@ -226,6 +226,18 @@ public:
      * FP32 on the device (MCMC_HIP_PRECISION_F32_MODEL, include/mcmc_hip.h).  Off = `Float` is
      * double everywhere, as in the reference (mcmc.h:43). */
     bool fastMode = false;
+    /* Extension, no counterpart in the reference and off by default: the reference's DiseaseSpread
+     * does not override sampleInitialConditions (the base returns {}, mcmc.h:112-114), so
+     * ChainManager(target, nReservoir, nChain) weighs the same point nReservoir times and seeds ONE
+     * chain.  With initialSpread = a > 0 a draw is the point the likelihood stood at when the first
+     * draw was made, every sampled coordinate moved by State::perturb's rule (mcmc.h:306-314),
+     *     x = x0 + (rnd.nextFloat() - .5f) * x0 * a,
+     * in the coords' order (behavior, discontinuousVals, betaMild, betaHigh, delay), then
+     * force_bounds.  The draw density is constant over its box, so the manager's importance
+     * weights (target density / draw density, mcmc.h:1331-1338) stay what they are up to a
+     * common factor; points that force_bounds moved to an edge carry the edge's weight. */
+    double initialSpread = 0;
+    std::vector<Float> initialCentre;      /* x0 above, taken at the first draw */
 
     static constexpr uint64_t kTrajectories = 10000000;             /* covid.h:207 */
 
@@ -273,6 +285,18 @@ public:
     }
     std::shared_ptr<SubspaceState> copy() const override { return std::make_shared<DiseaseSpread>(*this); }
 
+    /* one draw of the initialSpread extension above; false = off, nothing drawn, nothing moved */
+    bool sampleInitialPoint(pcg32& rnd) {
+        if (!(initialSpread > 0)) { initialCentre.clear(); return false; }   /* switched off: forget the centre */
+        if (initialCentre.empty()) initialCentre = pack();
+        std::vector<Float> x = initialCentre;
+        for (auto& v : x) v += (rnd.nextFloat() - .5f) * v * Float(initialSpread);
+        unpack(x.data());
+        for (const auto& f : fixed) coords[f.first][f.second] = initialCentre_at(f.first, f.second);
+        force_bounds();
+        return true;
+    }
+
     size_t nDaysTotal() const { return maxDelayDaysTilData + nPredictDays + data.deathsPerDay.size(); }
     size_t nBehavior() const { return data.deathsPerDay.size() - data.fixBehaviorInAdvance; }
     size_t nSampled() const { return nBehavior() + data.discontinuousVals.size() + 3; }
@@ -286,6 +310,11 @@ public:
     void unpack(const Float* x) {
         for (int k = 0; k < 5; ++k)
             for (auto& v : coords[k]) v = *x++;
+    }
+    Float initialCentre_at(size_t k, size_t i) const {
+        size_t off = 0;
+        for (size_t c = 0; c < k; ++c) off += coords[c].size();
+        return initialCentre[off + i];
     }
     /* derived output coords from mcmc_hip_derive's [9][size] block (covid.h:467-485) */
     void set_derived(const Float* curves) {
@@ -715,6 +744,7 @@ public:
      * likelihoods keep the base's empty answer (mcmc.h:112-114) and stay where they are. */
     std::vector<std::vector<Float>> sampleInitialConditions(pcg32& rnd) {
         if (ToyLikelihood* t = toy()) t->sampleInitialConditions(rnd);
+        else if (DiseaseSpread* ds = disease()) ds->sampleInitialPoint(rnd);     /* opt-in extension */
         isEvaluated = false;
         eval();
         return getInitialConditions();
@@ -1191,12 +1221,15 @@ protected:
     void draw_candidates(pcg32& rnd, size_t want, std::vector<std::pair<ICs, Float>>& out) {
         State& st = *target->state;
         ToyLikelihood* t = st.toy();
+        DiseaseSpread* ds = st.disease();
+        const bool draws = t || (ds && ds->initialSpread > 0);
         size_t rounds = 0;
         while (out.size() < want) {
             const size_t need = want - out.size();
             std::vector<ICs> cand;
             for (size_t i = 0; i < need; ++i) {
                 if (t) t->sampleInitialConditions(rnd);
+                else if (ds) ds->sampleInitialPoint(rnd);
                 ICs ic = {st.packed()};
                 for (size_t k = 1; k < st.state.size(); ++k) ic.push_back({});
                 cand.push_back(ic);
@@ -1205,10 +1238,10 @@ protected:
             weigh_candidates(cand, std::vector<Float>(need, 0.0), out);
             /* a likelihood that cannot draw gives the same point every time: the
              * reference would loop forever on a non-finite one */
-            if (out.size() == before && (!t || ++rounds > 1000))
+            if (out.size() == before && (!draws || ++rounds > 1000))
                 throw std::runtime_error("ChainManager: the state's log probability is not finite, no initial state can be drawn");
         }
-        if (t) st.setInitialConditions(out.back().first);
+        if (draws) st.setInitialConditions(out.back().first);
     }
 
     /* mcmc.h:1599-1650: importance resampling of the candidates.  Candidate k carries the log weight

@@ -88,7 +88,8 @@ PYBIND11_MODULE(mcmc, m) {
              py::keep_alive<1, 2>(), py::keep_alive<1, 3>())
         .def(py::init<const DiseaseData&, const DiseaseParams&, int, double, double, int, size_t, uint64_t>(),
              py::keep_alive<1, 2>(), py::keep_alive<1, 3>())
-        .def_readwrite("fastMode", &DiseaseSpread::fastMode)       /* extension: packed-FP32 convolution on the device */
+        .def_readwrite("fastMode", &DiseaseSpread::fastMode)       /* extension: FP32 convolution on the device */
+        .def_readwrite("initialSpread", &DiseaseSpread::initialSpread)   /* extension: 0 = the reference (one point) */
         .def("response_table", [](const DiseaseSpread& d) {
             py::array_t<Float> a({(size_t)MCMC_HIP_NCURVES, (size_t)MCMC_HIP_TRAJ_NDAYS});
             std::copy(d.responseTable->begin(), d.responseTable->end(), a.mutable_data());

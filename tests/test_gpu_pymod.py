@@ -287,3 +287,44 @@ def test_reservoir_and_generator_constructors():
     first = mcmc.ChainManager(gen, target, 2)
     first.run_all(1, 0, 1, 1)              # one step, one saved point = the initial conditions
     assert np.array_equal(first.saved_sample(0), pts[picks])
+
+
+def test_initial_spread_lets_a_manager_seed_distinct_covid_chains():
+    """DiseaseSpread.initialSpread (extension, off by default, no counterpart in the reference: its
+    DiseaseSpread keeps the base's empty sampleInitialConditions, mcmc.h:112-114, so a manager's chains
+    all start at one point -- the test above).  With a > 0 draw i is x0 + (nextFloat() - .5f) * x0 * a per
+    sampled coordinate in the coords' order (State::perturb's rule, mcmc.h:306-314) from the manager's
+    pcg32(0, 0), then force_bounds; fixed coordinates take their draw and keep their value."""
+    data, p, ds, state, target, cfg, m, tgt = _setup(T=1.0)
+    x0 = CC.initial_params(cfg)
+    nB, nD = cfg["nB"], cfg["n_disc"]
+    a = 0.05
+    ds.initialSpread = a
+    cm = mcmc.ChainManager(target, 6)
+    assert cm.n_chains() == 6
+    cm.run_all(1, 0, 1, 1)                  # one step, one saved point = the initial conditions
+    got = cm.saved_sample(0)
+    r = O.Rng(0, 0)
+    want = []
+    for _ in range(6):
+        f = np.array([np.float32(r.next_float()) - np.float32(0.5) for _ in range(cfg["dim"])], dtype=np.float64)
+        x = x0 + f * x0 * a
+        x = m.force_bounds(x)               # covid.h:629-646 (DISC's flags are >= 0: every plateau value is sampled)
+        want.append(x)
+    want = np.array(want)
+    assert np.array_equal(got, want)
+    assert len({tuple(row) for row in got}) == 6
+    # every chain starts from its own point and runs as the oracle's chain from there
+    oc = O.OracleChain(m, 3, want[2])       # chain 2 draws pcg32(0, 3), mcmc.h:1527
+    assert cm.get_chain(2).get_loglikes()[0] == oc.ll[0] + oc.ll[1]
+    # the reservoir constructor now finds distinct candidates to pick from (a hot target: at T = 1 the
+    # posterior is so peaked that one or two of 40 candidates carry all of the weight)
+    ds2 = _setup(T=1e7)
+    ds2[2].initialSpread = a
+    picked = mcmc.ChainManager(ds2[4], 40, 5)
+    assert picked.n_chains() == 5 and sum(picked.chain_weight(i) for i in range(5)) >= 5
+    picked.run_all(1, 0, 1, 1)
+    assert len({tuple(row) for row in picked.saved_sample(0)}) == 5
+    # off again: the reference's behaviour, one point
+    ds2[2].initialSpread = 0.0
+    assert mcmc.ChainManager(ds2[4], 6, 1).n_chains() == 1
