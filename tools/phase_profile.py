@@ -8,7 +8,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 adjust = int(sys.argv[3]) if len(sys.argv) > 3 else 25
 precision = os.environ.get("MCMC_PRECISION", "f64")        # or f32_model
-cfg, R, xs, s = bench.build_workload(0, n, 1, 1, precision=precision)
+regions = int(os.environ.get("MCMC_REGIONS", "0"))         # > 0: the multi-region workload (region days: MCMC_REGION_DAYS)
+if regions:
+    cfgs, R, xs, s = bench.build_region_workload(0, n, 1, 1, regions, int(os.environ.get("MCMC_REGION_DAYS", "500")))
+else:
+    cfg, R, xs, s = bench.build_workload(0, n, 1, 1, precision=precision)
 if adjust:
     s.run(0, 0, adjust, 1000000)
 s.step(16, 1.0, True)
