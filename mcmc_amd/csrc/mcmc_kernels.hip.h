@@ -260,7 +260,7 @@ __device__ inline LdsView stage_lds(const DevModel& M, double* lds, bool derive,
  * float tables the MFMA B operands are read from -- SEVEN floats per lag (no pad column: a block of MCMC_TM = 9
  * days x 7 curves fills 63 of the 64 MFMA columns) and three per lag for the corrections --, rows 0..MCMC_TM-1 of
  * both once more in 16-byte aligned rows for the sequential part, and one 64 x F32_TR_ROW float transposition
- * buffer per wave.  Lags reach horizon + MCMC_TM (last day of the last block against the first source day, one
+ * buffer per wave (one 32-column MFMA tile passes through it at a time).  Lags reach horizon + MCMC_TM (last day of the last block against the first source day, one
  * more for the pair alignment); sources all of whose lags are >= nLagRows are skipped in whole blocks, so no row
  * above nLagRows + 2 MCMC_TM + 2 is read either. */
 #ifndef MCMC_TM
@@ -270,9 +270,12 @@ __device__ inline LdsView stage_lds(const DevModel& M, double* lds, bool derive,
 #define F32_NE 3              /* ... of the correction table */
 #define F32_TAB_PAD 2         /* the B operand of the pair after the last one is requested too: rows -1 and -2 */
 #define F32_TAB_SLACK 2       /* the unused 64th column / lanes 27..31 of the correction tile read past the last row */
-#define F32_TR_ROW 76         /* floats per chain of the hand-over buffer: MCMC_TM days x 8 = 72 used */
+#define F32_DSPLIT (32 / F32_NC)   /* the day whose curves straddle the two 32-column MFMA tiles */
+#define F32_TR_JUNK 40        /* floats per chain of the hand-over buffer that carry data: 5 days x 8, one column tile at a time */
+#define F32_TR_ROW 44         /* ... and its row pitch (slot F32_TR_JUNK takes the unused columns' values) */
 #define F32_TR_FLOATS (MCMC_WAVE * F32_TR_ROW)
-static_assert(MCMC_TM * F32_NC <= 64 && MCMC_TM * F32_NE <= 32 && MCMC_TM * 8 <= F32_TR_ROW, "block does not fit the MFMA tiles");
+static_assert(MCMC_TM * F32_NC <= 64 && MCMC_TM * F32_NE <= 32 && (F32_DSPLIT + 1) * 8 <= F32_TR_JUNK &&
+              (MCMC_TM - F32_DSPLIT) * 8 <= F32_TR_JUNK && F32_TR_JUNK < F32_TR_ROW, "block does not fit the MFMA tiles");
 __host__ __device__ inline int lds_rows_f32(const DevModel& M) {
     const int a = M.simDays + MCMC_TM + 3, b = M.nLagRows + 2 * MCMC_TM + 6;
     return a < b ? a : b;

@@ -287,7 +287,7 @@ template <int T>
 __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsView& lds, float* tr, const float* hn_u,
                                              const float* he_u, int ws, int j0, int kLo, int eLo, int eHi,
                                              float (&ring0)[F32_RING][2], bool& haveRing0, unsigned lane, PhaseClock& pc) {
-    static_assert(T * F32_NC <= 64 && T * F32_NE <= 32 && T * 8 + 3 <= F32_TR_ROW, "block does not fit the MFMA tiles");
+    static_assert(T * F32_NC <= 64 && T * F32_NE <= 32 && T * 4 <= F32_TR_JUNK, "block does not fit the MFMA tiles");
     constexpr int HOFF = 2 * T;
     const int half = (int)(lane >> 5), n = (int)(lane & 31);
     float16v_t C[2][2];
@@ -346,38 +346,63 @@ __device__ __forceinline__ void mfma_sources(float2_t (&acc)[P_N][T], const LdsV
         if (tailE) mfma_once<1>(Ce, half ? 0.0f : aes[0], half ? 0.0f : aes[1], lds.tabN, (1 - half + F32_TAB_PAD) * F32_NE + n);
     }
     pc.stamp(PH_CHUNKS_E);
-    /* MFMA layout -> chain per lane through the wave's LDS buffer: element v of tile (mt, nt) is chain
-     * 2 (8 (v/4) + 4 half + v%4) + mt, column 32 nt + n = (day, curve) 7 day + curve; a chain's row holds 8
-     * floats per day, so it comes back as two 16-byte reads per day (rows of 76 floats: lanes 8 apart share a
-     * bank group, which a 16-byte read of 64 lanes needs eight passes for anyway) */
+    /* MFMA layout -> chain per lane through the wave's LDS buffer, one column tile at a time (the buffer is a
+     * quarter of the wave's LDS share then: two workgroups fit a CU): element v of tile (mt, nt) is chain
+     * 2 (8 (v/4) + 4 half + v%4) + mt, column 32 nt + n = (day, curve) 7 day + curve.  Tile 0 holds days
+     * 0..F32_DSPLIT (of the last one the curves 0..3), tile 1 days F32_DSPLIT (curves 4..6) .. T-1; a chain's row
+     * holds 8 floats per day and comes back as 16-byte reads (rows of 44 floats: lanes 8 apart share a bank group,
+     * which a 16-byte read of 64 lanes needs eight passes for anyway). */
+    constexpr int DS = F32_DSPLIT;
+    static_assert(32 % F32_NC == 4 && (DS + 1) * 8 <= F32_TR_JUNK && (T - DS) * 8 <= F32_TR_JUNK && T > DS,
+                  "the tile boundary has to fall between a day's two 16-byte halves");
     const int col1 = 32 + n;
-    /* columns past the block's last curve go to the row's unused tail instead of being predicated off */
-    const int off0 = n < T * F32_NC ? (n / F32_NC) * 8 + n % F32_NC : T * 8;
-    const int off1 = col1 < T * F32_NC ? (col1 / F32_NC) * 8 + col1 % F32_NC : T * 8 + 1;
+    const int off0 = (n / F32_NC) * 8 + n % F32_NC;
+    /* the 64th column goes to the row's unused tail instead of being predicated off */
+    const int off1 = col1 < T * F32_NC ? (col1 / F32_NC - DS) * 8 + col1 % F32_NC : F32_TR_JUNK;
+    const float4_t* mine = (const float4_t*)(tr + lane * F32_TR_ROW);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            float* row = tr + (2 * (8 * (v / 4) + 4 * half + (v % 4)) + mt) * F32_TR_ROW;
-            row[off0] = C[mt][0][v];
-            row[off1] = C[mt][1][v];
-        }
+        for (int v = 0; v < 16; ++v)
+            tr[(2 * (8 * (v / 4) + 4 * half + (v % 4)) + mt) * F32_TR_ROW + off0] = C[mt][0][v];
     __builtin_amdgcn_s_waitcnt(0xc07f);                 /* lgkmcnt(0): the wave's own LDS writes have landed */
     __builtin_amdgcn_wave_barrier();
-    const float4_t* mine = (const float4_t*)(tr + lane * F32_TR_ROW);
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const float4_t lo = mine[2 * t], hi = mine[2 * t + 1];
+    for (int t = 0; t <= DS; ++t) {
+        const float4_t lo = mine[2 * t];
         acc[P_INF][t] = float2_t{lo[0], lo[1]};
         acc[P_IM][t] = float2_t{lo[2], lo[3]};
-        acc[P_SR][t] = float2_t{hi[0], hi[1]};
-        acc[P_D][t] = float2_t{hi[2], 0.0f};
+        if (t < DS) {
+            const float4_t hi = mine[2 * t + 1];
+            acc[P_SR][t] = float2_t{hi[0], hi[1]};
+            acc[P_D][t] = float2_t{hi[2], 0.0f};
+        }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);                 /* read back before the buffer is written again */
     __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+            tr[(2 * (8 * (v / 4) + 4 * half + (v % 4)) + mt) * F32_TR_ROW + off1] = C[mt][1][v];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = DS; t < T; ++t) {
+        const float4_t hi = mine[2 * (t - DS) + 1];
+        acc[P_SR][t] = float2_t{hi[0], hi[1]};
+        acc[P_D][t] = float2_t{hi[2], 0.0f};
+        if (t > DS) {
+            const float4_t lo = mine[2 * (t - DS)];
+            acc[P_INF][t] = float2_t{lo[0], lo[1]};
+            acc[P_IM][t] = float2_t{lo[2], lo[3]};
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
     if (withE || tailE) {
         /* the corrections' tile through the same buffer: column n = (day, curve) 3 day + curve, 4 floats per day */
-        const int offE = n < T * F32_NE ? (n / F32_NE) * 4 + n % F32_NE : T * 8 + 2;
+        const int offE = n < T * F32_NE ? (n / F32_NE) * 4 + n % F32_NE : F32_TR_JUNK;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
