@@ -310,7 +310,7 @@ __device__ inline LdsView stage_lds_f32(const DevModel& M, double* lds) {
     }
     for (int i = threadIdx.x; i < M.nData; i += blockDim.x) {
         dea[i] = M.deaths[i];
-        sg2[i] = M.sigma2[i];
+        sg2[i] = 1.0 / M.sigma2[i];     /* this image holds the RECIPROCAL: the fast mode multiplies (eval_model_f32) */
     }
     /* the global float tables have 8 / 4 floats per lag and zeros from nLagRows on (mcmc_hip_set_tables) */
     for (int i = threadIdx.x; i < rowsAll * F32_NC; i += blockDim.x) {
