@@ -35,12 +35,13 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
     every = int(sys.argv[3]) if len(sys.argv) > 3 else 100
     adjust = int(sys.argv[4]) if len(sys.argv) > 4 else 200
-    cfg, R, xs, s = bench.build_workload(0, n, 1, 1)
+    precision = os.environ.get("MCMC_PRECISION", "f64")      # f32_model: the same chains in the fast mode
+    cfg, R, xs, s = bench.build_workload(0, n, 1, 1, precision=precision)
     dim = cfg["dim"]
     names = ["betaMild", "betaHigh", "delay"]
     t0 = time.perf_counter()
     s.run(0, 0, adjust, 1000000)
-    print(json.dumps({"adapted": adjust * 20, "seconds": time.perf_counter() - t0,
+    print(json.dumps({"precision": precision, "adapted": adjust * 20, "seconds": time.perf_counter() - t0,
                       "stepsize_mean": float(np.mean(s.stepsizes()))}), flush=True)
     n_fetch = steps // every
     trace = np.empty((n, n_fetch, 4))
