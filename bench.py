@@ -15,6 +15,11 @@ step-size adaptation (untimed, like the adjust phase that precedes sampling in
 MetropolisChain::run), then W warm-up steps.  All inputs are resident in HBM before the timed
 region.  Arithmetic is FP64 as in the reference (`using Float = double`, mcmc.h:43).
 
+Other BASELINE.json configurations through the same line (`--config`): c1 = configs[1] (1 024 chains x 200
+days: a small ensemble, 16 waves on a chip of 1 024 SIMDs -- `config.occupancy` says so), c2 = the default,
+c3 = configs[3] (64-rung ladders), c4 = configs[4] (50 regions x 500 days x 131 072 chains).  `--total-chains N`
+splits a FIXED total over the ranks (strong scaling; the default gives every GPU 65 536 chains = weak).
+
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -59,9 +64,9 @@ def build_workload(device, n_chains, first_chain_id, contract, n_data=N_DATA, pr
     cfg = CC.synthetic_config(n_data, forward, disease_params=dp, initial_beta_mild=BETA_MILD,
                               initial_beta_high=BETA_HIGH, contract=contract)
     x0 = CC.initial_params(cfg)
-    # one global IC stream so that chain i has the same start on any sharding
-    xs_all = H.perturb_ics(x0, first_chain_id - 1 + n_chains, 0.01)
-    xs = xs_all[first_chain_id - 1:]
+    # one global IC stream so that chain i has the same start on any sharding; a rank jumps the generator to
+    # its first chain instead of drawing everybody else's (tests/test_host_cpu.py: jumped == sliced)
+    xs = H.perturb_ics(x0, n_chains, 0.01, first_chain=first_chain_id - 1)
     sampler = H.CovidSampler(cfg, R, device, precision=precision)
     sampler.set_chains(xs, first_chain_id=first_chain_id)
     return cfg, R, xs, sampler
@@ -87,7 +92,7 @@ def build_region_workload(device, n_chains, first_chain_id, contract, n_regions,
     cfgs = [CC.synthetic_config(n_data, forward, pop_size=int(6e7 / (1 + 0.25 * (r % 8))), cap0=7500.0 / (1 + r % 5),
                                 cap_incr_rate=100.0 - r % 50, **kw) for r in range(n_regions)]
     x0 = np.concatenate([CC.initial_params(c) for c in cfgs])
-    xs = H.perturb_ics(x0, first_chain_id - 1 + n_chains, 0.01)[first_chain_id - 1:]
+    xs = H.perturb_ics(x0, n_chains, 0.01, first_chain=first_chain_id - 1)
     sampler = H.CovidSampler(cfgs[0], R, device)
     sampler.set_regions(cfgs)
     sampler.set_chains(xs, first_chain_id=first_chain_id)
@@ -133,7 +138,7 @@ def cpu_baseline(cfg, R10, xs, stepsizes, contract, seconds=12.0):
 
     lean, lean_s = timed(O.Model(cfg, R11, contract=contract), "lean: table shared by pointer")
     out = {"value": lean, "unit": "MH steps/s", "cores": threads, "cores_visible": visible, "kind": "port",
-           "sample": f"{lean_s} of the same 365-day workload from the same adapted state "
+           "sample": f"{lean_s} of the same {cfg['n_data']}-day workload from the same adapted state "
                      f"(oracle/mcmc_oracle.c, -O3 -mavx2 -mfma, {threads} pthreads = the box's CPU share per GPU)"}
     try:
         grid = O.traj_generate(O.DiseaseParams(**{k: float(v) for k, v in CC.ipynb_disease_params().items()}))
@@ -171,14 +176,70 @@ def ess_finish(tot, n_saved, n_steps, thinning, ranks):
     rhat, _ = rhat_ess(tot[5:], 3, n_saved)                                          # Gelman-Rubin over all chains
     converged = bool(np.all(np.isfinite(rhat)) and float(np.max(rhat)) < 1.1)
     out = {"converged": converged, "acceptance": float(tot[1] / (n * n_steps)), "rhat": dict(zip(names, map(float, rhat))),
+           # Geyer's estimate inside each chain's own trace, averaged over chains: how fast a chain decorrelates
+           # around the level it is at.  It is an ESS of the posterior only if `converged`.
+           "ess_per_step_within_chain": {nm: float(tot[2 + j] / (n * n_steps)) for j, nm in enumerate(names)},
            "sample": f"{int(n)} chains ({ranks} rank(s)) x {n_steps} steps after the adaptation, every {thinning}th point, "
                      "Geyer initial positive sequence per chain, summed over chains; R-hat over all of them"}
     if converged:
-        out["ess_per_step"] = {nm: float(tot[2 + j] / (n * n_steps)) for j, nm in enumerate(names)}
+        out["ess_per_step"] = dict(out["ess_per_step_within_chain"])
     else:
-        out["note"] = ("R-hat >= 1.1: the chains have not reached stationarity in this stretch (a 358-dimensional "
-                       "random-walk sampler needs far more than a benchmark's steps), so no ESS/s is quoted")
+        out["note"] = ("R-hat >= 1.1: the chains have not reached stationarity in this stretch (a random-walk sampler in "
+                       "this many dimensions needs far more than a benchmark's steps), so the within-chain figure is NOT "
+                       "a posterior ESS and no covid ESS/s is quoted; `ess_toy` holds a converged ESS/s (GPU and CPU) on "
+                       "the targets of BASELINE configs[0], where the reference's sampler mixes")
     return out
+
+
+def toy_ess_leg(device, n_chains, threads):
+    """ESS/s -- the second half of BASELINE.json's metric -- on workloads where the reference's sampler reaches
+    stationarity within a benchmark: the toy targets of BASELINE configs[0] under MetropolisChain::run
+    (mcmc.h:1005-1138) through mcmc_hip_toy_run, n_chains chains in one launch; the CPU oracle runs the same
+    chains (bit-identical, tests/test_gpu_toy.py) on the box's host threads.  ESS = Geyer per chain over the
+    recorded post-burn-in points, summed over chains; ESS/s = that sum / wall time of the WHOLE run (adjust
+    phase included, upload and download included on the GPU side)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from mcmc_amd.sharding import ess_geyer, moment_sums, rhat_ess
+    from oracle import oracle as O
+    legs = {}
+    n_rec = min(4096, n_chains)
+    # name, x0, (nSamples, nBurnin, nAdjust, thinning), difficulty, scalars of the ESS
+    for name, x0, sched, diff, k_use in [("mylike1", [1.0, 1.0, 1.0], (10000, 2000, 500, 5), 1.0, 3),
+                                          ("rosenbrock", [1.0, 1.0], (60000, 20000, 500, 20), 100.0, 2)]:
+        ns, nb, na, th = sched
+        steps_per_chain = 20 * na + ns
+        X = np.tile(np.array(x0), (n_chains, 1))
+        H.toy_run(name, X[:64], 10, 0, 1, 1, difficulty=diff, first_chain_id=1, device=device, record=False)   # module load
+        t0 = time.perf_counter()
+        H.toy_run(name, X, ns, nb, na, th, difficulty=diff, first_chain_id=1, device=device, record=False)
+        gpu_wall = time.perf_counter() - t0
+        rec = H.toy_run(name, X[:n_rec], ns, nb, na, th, difficulty=diff, first_chain_id=1, device=device)
+        pts = rec["samples"][:, :, :k_use]                                   # [n_rec][n_saved][k]
+        n_saved = pts.shape[1]
+        ess = np.array([ess_geyer(pts[:, :, j]).mean() for j in range(k_use)])   # per chain
+        rhat, _ = rhat_ess(moment_sums(pts), k_use, n_saved)
+        # CPU: the oracle's run of the same schedule, one chain per call, `threads` at a time
+        n_cpu = 4 * threads
+        fn = {"mylike1": lambda cid: O.mylike1_run(cid, ns, nb, na, th),
+              "rosenbrock": lambda cid: O.rosenbrock_run(diff, 1.0, cid, x0, ns, nb, na, th)}[name]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            cpu = list(ex.map(fn, range(1, n_cpu + 1)))
+        cpu_wall = time.perf_counter() - t0
+        same = all(np.array_equal(cpu[c][1][:, :k_use], pts[c]) for c in range(min(n_cpu, n_rec)))
+        worst = float(ess.min())
+        legs[name] = {"converged": bool(np.all(np.isfinite(rhat)) and float(np.max(rhat)) < 1.1),
+                      "rhat_max": float(np.max(rhat)), "ess_per_chain_worst_coordinate": worst,
+                      "ess_per_step": worst / steps_per_chain,
+                      "gpu": {"chains": n_chains, "wall_s": gpu_wall, "steps_per_s": n_chains * steps_per_chain / gpu_wall,
+                              "ess_per_s": worst * n_chains / gpu_wall},
+                      "cpu": {"chains": n_cpu, "threads": threads, "wall_s": cpu_wall,
+                              "steps_per_s": n_cpu * steps_per_chain / cpu_wall, "ess_per_s": worst * n_cpu / cpu_wall},
+                      "gpu_over_cpu_ess_per_s": (worst * n_chains / gpu_wall) / (worst * n_cpu / cpu_wall),
+                      "cpu_chains_bit_identical_to_gpu": bool(same),
+                      "schedule": f"run({ns}, {nb}, {na}, {th}): {steps_per_chain} MH steps per chain, {n_saved} recorded points; "
+                                  f"ESS from the first {n_rec} chains"}
+    return legs
 
 
 def side_leg(cfg, R, device, start, first_id, args, precision, contract):
@@ -201,7 +262,7 @@ def side_leg(cfg, R, device, start, first_id, args, precision, contract):
     n = start[0].shape[0]
     s.close()
     ksec, launches = t1["step_kernel_s"] - t0["step_kernel_s"], t1["launches"] - t0["launches"]
-    flops = 16.0 * pairs + (10.0 * N_DATA + 7.0 * cfg["nB"]) * n * steps
+    flops = 16.0 * pairs + (10.0 * cfg["n_data"] + 7.0 * cfg["nB"]) * n * steps
     return {"value": n * steps / wall, "unit": "MH steps/s", "steps": steps, "ms_per_step": 1e3 * wall / steps,
             "kernel_ms_per_launch": 1e3 * ksec / max(launches, 1), "achieved": flops / ksec / 1e12,
             "executed_tflops": 14.0 * pairs_exec / ksec / 1e12, "unit_roofline": "TFLOP/s"}
@@ -212,7 +273,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--chains-per-gpu", type=int, default=CHAINS_PER_GPU)
+    ap.add_argument("--chains-per-gpu", type=int, default=None, help=f"weak scaling (default {CHAINS_PER_GPU} per GPU)")
+    ap.add_argument("--total-chains", type=int, default=None,
+                    help="STRONG scaling: this many chains in total, split over the ranks by contiguous chain-id range")
+    ap.add_argument("--n-data", type=int, default=None, help=f"data days of the single-region series (default {N_DATA})")
+    ap.add_argument("--config", default=None, choices=["c1", "c2", "c3", "c4"],
+                    help="BASELINE.json configs[1..4]: c1 = 1024 chains x 200 days, c2 = the default (65536 x 365), "
+                         "c3 = 64-rung ladders, c4 = 50 regions x 500 days x 131072 chains; explicit flags win")
     ap.add_argument("--contract", type=int, default=int(os.environ.get("MCMC_BENCH_CONTRACT", "1")))
     ap.add_argument("--adjust", type=int, default=int(os.environ.get("MCMC_BENCH_ADJUST", "25")),
                     help="adjust-phase iterations (20 MH steps each, mcmc.h:1083-1119) run untimed before the warm-up")
@@ -223,6 +290,7 @@ def main():
                     help="arithmetic of the MAIN leg; f32_model (fast mode) is for profiling that kernel only: "
                          "the line then says dtype f32+f64 and is not the headline metric")
     ap.add_argument("--ess-chains", type=int, default=4096, help="chains of the ESS leg (0: skip it)")
+    ap.add_argument("--no-toy-ess", action="store_true", help="skip the converged-ESS/s leg on the toy targets (N=1 only)")
     ap.add_argument("--ess-steps", type=int, default=2000)
     # BASELINE.json configs[3] (extension): ladders of K temperatures, whole ladders per GPU
     ap.add_argument("--ladder", type=int, default=0, help="temperatures per ladder (0: no tempering)")
@@ -235,6 +303,17 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--device", type=int, default=None, help="HIP ordinal for every rank (default: LOCAL_RANK)")
     args = ap.parse_args()
+    preset = {"c1": dict(chains_per_gpu=1024, n_data=200), "c2": {}, "c3": dict(ladder=64),
+              "c4": dict(regions=50, chains_per_gpu=131072)}.get(args.config or "c2")
+    for k, v in preset.items():
+        if getattr(args, k) in (None, 0):
+            setattr(args, k, v)
+    if args.total_chains is not None and args.chains_per_gpu is not None:
+        raise SystemExit("bench.py: --total-chains (strong scaling) and --chains-per-gpu (weak) exclude each other")
+    if args.chains_per_gpu is None:
+        args.chains_per_gpu = CHAINS_PER_GPU
+    if args.n_data is None:
+        args.n_data = N_DATA
 
     # ---- one process per GPU: become the launcher if this is a plain `--gpus N` call (nothing in
     # this process has touched HIP or torch yet) ----
@@ -262,9 +341,19 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    n_chains = args.chains_per_gpu
-    first_id = 1 + rank * n_chains                       # contiguous chain-id ranges
-    n_data = N_DATA
+    from mcmc_amd.sharding import shard_range
+    if args.total_chains is not None:                    # strong scaling: a fixed total, mcmc.h:1487's ids i+1
+        lo, hi = shard_range(args.total_chains, rank, world)
+        if args.ladder and (lo % args.ladder or hi % args.ladder):
+            raise SystemExit("bench.py: --total-chains must give every rank whole ladders")
+        n_chains, first_id, n_total = hi - lo, 1 + lo, args.total_chains
+        if n_chains < 1:
+            raise SystemExit(f"bench.py: rank {rank} of {world} gets no chain out of {args.total_chains}")
+    else:
+        n_chains = args.chains_per_gpu
+        first_id = 1 + rank * n_chains                   # contiguous chain-id ranges
+        n_total = world * n_chains
+    n_data = args.n_data
     if args.regions:
         if args.ladder or args.precision != "f64":
             raise SystemExit("bench.py: --regions runs without --ladder, in f64")
@@ -273,7 +362,7 @@ def main():
         cfg = dict(cfgs[0])
         cfg["dim"] = s.dim
     else:
-        cfg, R, xs, s = build_workload(device, n_chains, first_id, args.contract, precision=args.precision)
+        cfg, R, xs, s = build_workload(device, n_chains, first_id, args.contract, n_data=n_data, precision=args.precision)
     fast_main = args.precision != "f64"
     peak = PEAK_FP32_VECTOR_TFLOPS if fast_main else PEAK_FP64_VECTOR_TFLOPS
 
@@ -287,7 +376,7 @@ def main():
         s.run(0, 0, args.adjust, 1000000)                # step-size adaptation only, nothing recorded
     if args.ladder:
         temps = np.geomspace(1.0, args.ladder_tmax, args.ladder)
-        s.set_ladder(temps, swap_seed=1, first_ladder=rank * (n_chains // args.ladder))
+        s.set_ladder(temps, swap_seed=1, first_ladder=(first_id - 1) // args.ladder)
     s.step(args.warmup, 1.0, True)
     adapted = (s.params(), s.stepsizes()) if not args.regions else None   # start of the CPU leg and the side legs
     s.pair_count(reset=True)
@@ -325,22 +414,24 @@ def main():
         ess_tot = allreduce_sum(pieces)
 
     if rank == 0:
-        total_steps = world * n_chains * args.steps
+        total_steps = n_total * args.steps
         value = total_steps / dt
+        n_simd = 4 * torch.cuda.get_device_properties(device).multi_processor_count
+        n_waves = (n_chains + 63) // 64
         # roofline of the dominant kernel (mh_step_kernel) on this rank
         ksec = t_after["step_kernel_s"] - t_before["step_kernel_s"]
         launches = t_after["launches"] - t_before["launches"]
         pairs = s.pair_count()                            # sum over chains/steps, SURVEY 8d work unit
         pairs_exec = s.executed_pair_count()
         nB = cfg["nB"]
-        flops = 16.0 * pairs + (10.0 * n_data + 7.0 * nB) * n_chains * args.steps
+        flops = 16.0 * pairs + (10.0 * n_data + 7.0 * nB) * n_chains * args.steps   # the ALGORITHMIC count
         flops_exec = 14.0 * pairs_exec                    # the multiply-adds the kernel ran: 7 families, visible days
         achieved = flops / ksec / 1e12
         # HBM-side traffic: not measured in this run (PMC counters need rocprofv3); taken from the
         # committed profile of the same kernel and scaled per chain-step, with its source named
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_fast_mode.json" if fast_main else "traffic_latest.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and n_data == N_DATA and not args.regions:     # bytes per chain-step depend on the series length
             try:
                 tj = json.load(open(tpath))
                 per_chain_step = tj["hbm_bytes_per_launch"] / (tj.get("chains", CHAINS_PER_GPU) * tj.get("steps_per_launch", STEPS_PER_LAUNCH))
@@ -354,17 +445,25 @@ def main():
             "metric": "MH steps/sec (whole node) on covid model, 64k chains; ESS/sec vs CPU TBB",   # BASELINE.json's string; ESS/s is in "ess"
             "value": value, "unit": "MH steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
+            "scaling": "strong" if args.total_chains is not None else "weak", "vs_baseline": None,
             "dtype": ("f32 %s (renewal convolution) + f64 -- FAST MODE, not the headline metric" % ("MFMA" if args.precision == "f32_model" else "packed FMA")) if fast_main else "f64",
             "data": "synthetic",
             "config": {"workload": (f"multi-region covid.h model (extension), {args.regions} regions x {n_data} data days, "
                                     f"{n_chains} independent chains per GPU, systematic scan over the regions, chain-sharded "
                                     "(BASELINE.json configs[4]) -- NOT the headline workload") if args.regions else
-                                   (f"covid.h model, {n_chains} independent chains per GPU, 365-day synthetic "
-                                    "series, chain-sharded (BASELINE.json configs[2])"),
+                                   (f"covid.h model, {n_chains} independent chains per GPU, {n_data}-day synthetic "
+                                    "series, chain-sharded (BASELINE.json configs[%s])" %
+                                    ("1" if (n_chains, n_data) == (1024, 200) else "3" if args.ladder else
+                                     "2" if n_data == N_DATA else "2 shape, other length")),
                        **({"regions": args.regions, "dim_per_region": cfgs[0]["dim"]} if args.regions else {}),
-                       "chains_per_gpu": n_chains, "n_data": n_data, "dim": cfg["dim"],
+                       "chains_per_gpu": n_chains, "chains_total": n_total, "n_data": n_data, "dim": cfg["dim"],
+                       # one chain per lane: how much of the chip this ensemble can occupy at all
+                       "occupancy": {"waves_per_gpu": n_waves, "simds_per_gpu": n_simd, "frac": min(1.0, n_waves / n_simd)},
                        "size": cfg["size"], "fp_contract": "fma" if args.contract else "strict",
+                       "fp_contract_models": ("a -march=native build of the reference (enoki_set_native_flags, CMakeLists.txt:98) "
+                                              "in which the compiler contracts project()'s `dest[d+k] += n*cumsum` (covid.h:384) "
+                                              "into one fused multiply-add; every other expression is a separate mul / add") if args.contract
+                                             else "the C++ source semantics: every projection term a multiply, then an add",
                        "adjust_iterations_before_timing": args.adjust,
                        **({"ladder": {"temperatures": args.ladder, "t_max": args.ladder_tmax,
                                       "swap_every": args.swap_every}} if args.ladder else {}),
@@ -376,6 +475,10 @@ def main():
                          "steps_per_launch": args.steps / max(launches, 1),
                          "algorithmic_flops_per_launch": flops / max(launches, 1),
                          "frac_of_fp32_vector_peak": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                         # `achieved` / `frac` follow the contract's definition (SURVEY 8d's algorithmic FLOP per step x the
+                         # steps of a launch / the launch's duration); what the FMA pipe itself executes is smaller:
+                         "frac_counts": "algorithmic FLOP of the reference's formulation (8 compartments, full horizon), SURVEY 8d",
+                         "achieved_executed": flops_exec / ksec / 1e12, "frac_executed": flops_exec / ksec / 1e12 / peak,
                          # what the kernel's FMA pipe really did: the reference-algorithmic figure above counts 8
                          # compartments over maxDelay+nPredict+nData days, the kernel runs 7 over maxDelay+nData
                          "executed": {"tflops": flops_exec / ksec / 1e12, "frac": flops_exec / ksec / 1e12 / peak,
@@ -426,6 +529,8 @@ def main():
                 if "cpu_baseline" in out:
                     e["cpu_ess_per_s"] = worst * out["cpu_baseline"]["value"]
             out["ess"] = e
+        if world == 1 and not args.no_toy_ess and not args.no_cpu_baseline and side:
+            out["ess_toy"] = toy_ess_leg(device, 65536, host_threads()[0])
         print(json.dumps(out), flush=True)
     s.close()
     if dist is not None:

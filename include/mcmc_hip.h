@@ -94,6 +94,12 @@ void mcmc_host_default_disease_params(mcmc_disease_params* p);          /* covid
  * per-coordinate rule of State::perturb (mcmc.h:306-314). */
 int mcmc_host_perturb_ics(const double* x0, int32_t dim, int64_t n_chains, double a,
                           uint64_t initstate, uint64_t initseq, double* out);
+/* The chains [first_chain, first_chain + n_chains) of that same sequence without drawing the ones
+ * before them: the generator is moved first_chain * dim draws ahead in O(log) steps, so a rank that
+ * owns a chain-id range far into the sequence sets up in time proportional to ITS chains.  (No
+ * counterpart in the reference, whose managers draw every chain's start serially, mcmc.h:1319-1346.) */
+int mcmc_host_perturb_ics_from(const double* x0, int32_t dim, int64_t first_chain, int64_t n_chains,
+                               double a, uint64_t initstate, uint64_t initseq, double* out);
 
 /* --- context ------------------------------------------------------------------------
  * Replaces constructing DiseaseSpread/SmoothnessPrior/State/Target (covid.h:294,
@@ -131,6 +137,15 @@ int mcmc_hip_set_regions(mcmc_hip_ctx* ctx, int32_t n_regions, const int32_t* po
 int32_t mcmc_hip_n_regions(const mcmc_hip_ctx* ctx);
 int mcmc_hip_get_region_loglike(mcmc_hip_ctx* ctx, double* out /*[n_chains][n_regions][2]*/);
 int mcmc_hip_get_region_stepsizes(mcmc_hip_ctx* ctx, double* out /*[n_chains][n_regions]*/);
+/* What a multi-region chain carries beyond mcmc_hip_set_state's four arrays (checkpoint / resume; same
+ * role as there, mcmc.h:1141-1199,1376-1418): the position of the systematic scan -- the number of
+ * random-subspace steps since set_chains; the next head is scan_position mod n_regions, a
+ * given-subspace step reuses (scan_position - 1) mod n_regions -- and every region's own
+ * stepsizeCorrectionFac, [n_chains][n_regions] as get_region_stepsizes returns it (set_chains takes one
+ * step size per chain and gives it to every region; NULL keeps that).  Call after set_chains (which
+ * resets the scan to 0).  On a single-region context the position is kept and has no effect. */
+int mcmc_hip_get_scan_position(mcmc_hip_ctx* ctx, int64_t* out);
+int mcmc_hip_set_region_state(mcmc_hip_ctx* ctx, int64_t scan_position, const double* region_stepsizes);
 
 /* Arithmetic of the model time-stepper.  No counterpart in the reference, whose only
  * arithmetic is `using Float = double` (mcmc.h:43) = MCMC_HIP_PRECISION_F64, the default and
@@ -166,7 +181,10 @@ int mcmc_hip_set_chains(mcmc_hip_ctx* ctx, int64_t n_chains, const double* param
  * get_rng_state -- a MetropolisChain seeds `rnd` ONCE in its constructor and keeps drawing from it
  * across run() calls (mcmc.h:994-999) --; loglike [n][2] of get_loglike; mean [n][dim] = the
  * running `mean` a second run() keeps adding to (mcmc.h:1002,1064-1065,1133-1134; get_mean);
- * accept_counts [n] = run()'s nAccept.  params + stepsizes + these four are a chain's whole state. */
+ * accept_counts [n] = run()'s nAccept.  params + stepsizes + these four are a chain's whole state
+ * in the reference's single-region State; a multi-region chain (set_regions) has loglike
+ * [n][n_regions][2] here and ALSO needs mcmc_hip_set_region_state (scan position, per-region step
+ * sizes) to continue bit for bit. */
 int mcmc_hip_set_state(mcmc_hip_ctx* ctx, const uint64_t* rng_state, const double* loglike,
                        const double* mean, const int32_t* accept_counts);
 
@@ -217,7 +235,8 @@ int mcmc_hip_derive(mcmc_hip_ctx* ctx, int64_t n, const double* params, double* 
 
 /* mcmc_hip_eval for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE (its chains
  * allocate freely, e.g. copy() at covid.h:501): this variant exists for callers that must not
- * reach hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid it.
+ * reach hipMalloc -- tight serving loops, harnesses that forbid allocation after set-up.  (It is not
+ * itself capturable into a HIP graph: it runs on the context's own stream and synchronises it.)
  * Same kernels and results as mcmc_hip_eval (bit for bit), but params_dev [n][dim] and ll_out_dev
  * [n][2] are DEVICE pointers on the context's GPU, and the kernels' scratch (tiled parameters,
  * per-lane histories, weighted deaths, results) is a file-scope device array of 16 MiB that every
@@ -225,7 +244,9 @@ int mcmc_hip_derive(mcmc_hip_ctx* ctx, int64_t n, const double* params, double* 
  * it returns after its kernels have finished (it synchronises the context's stream).  n is
  * limited by that array: mcmc_hip_eval_static_max(ctx) vectors for this model (960 at 365 data
  * days); a larger n is rejected with MCMC_HIP_EINVAL.  Every call on one GPU shares that GPU's
- * array, from any context: calls that overlap on one GPU race -- serialise them. */
+ * array, from any context: within one process the library serialises them (a per-device lock held
+ * until the call's kernels have finished); calls from different PROCESSES do not share the array
+ * (each process image has its own copy). */
 int mcmc_hip_eval_static(mcmc_hip_ctx* ctx, int64_t n, const double* params_dev, double* ll_out_dev);
 int64_t mcmc_hip_eval_static_max(const mcmc_hip_ctx* ctx);
 

@@ -253,6 +253,9 @@ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 constexpr int kMaxDevices = 64;
 double* g_scratch_of_device[kMaxDevices];
 std::mutex g_scratch_mu;
+/* one lock per device's array: eval_static holds it from its memset to the end of its kernels, so calls from
+ * several host threads (contexts have streams of their own) take turns instead of racing on the array */
+std::mutex g_scratch_busy[kMaxDevices];
 int static_scratch_for(int device, double** out) {
     if (device < 0 || device >= kMaxDevices) return fail(MCMC_HIP_EINVAL, "device ordinal %d beyond %d", device, kMaxDevices);
     std::lock_guard<std::mutex> lock(g_scratch_mu);
@@ -419,6 +422,32 @@ int mcmc_host_perturb_ics(const double* x0, int32_t dim, int64_t n_chains, doubl
     if (!x0 || !out || dim < 1 || n_chains < 0) return fail(MCMC_HIP_EINVAL, "perturb_ics: bad arguments");
     HostPcg r;
     pcg32_seed(r.state, r.inc, initstate, initseq);
+    for (int64_t c = 0; c < n_chains; ++c)
+        for (int k = 0; k < dim; ++k)
+            out[c * dim + k] = x0[k] + (r.next_float() - .5f) * x0[k] * a;   /* mcmc.h:310 */
+    return 0;
+} MCMC_ABI_GUARD
+
+/* pcg32's stream `delta` draws further on, in O(log delta): the LCG state after delta steps is
+ * mult^delta * state + inc * (mult^delta - 1)/(mult - 1), both factors formed by repeated squaring
+ * (Brown, "Random number generation with arbitrary strides"; what the PCG library calls advance) */
+static void pcg32_jump(HostPcg& r, uint64_t delta) {
+    uint64_t curMult = 0x5851f42d4c957f2dULL, curPlus = r.inc, accMult = 1, accPlus = 0;
+    while (delta > 0) {
+        if (delta & 1) { accMult *= curMult; accPlus = accPlus * curMult + curPlus; }
+        curPlus = (curMult + 1) * curPlus;
+        curMult *= curMult;
+        delta >>= 1;
+    }
+    r.state = accMult * r.state + accPlus;
+}
+
+int mcmc_host_perturb_ics_from(const double* x0, int32_t dim, int64_t first_chain, int64_t n_chains, double a,
+                               uint64_t initstate, uint64_t initseq, double* out) try {
+    if (!x0 || !out || dim < 1 || n_chains < 0 || first_chain < 0) return fail(MCMC_HIP_EINVAL, "perturb_ics_from: bad arguments");
+    HostPcg r;
+    pcg32_seed(r.state, r.inc, initstate, initseq);
+    pcg32_jump(r, (uint64_t)first_chain * (uint64_t)dim);            /* one nextUInt per coordinate drawn so far */
     for (int64_t c = 0; c < n_chains; ++c)
         for (int k = 0; k < dim; ++k)
             out[c * dim + k] = x0[k] + (r.next_float() - .5f) * x0[k] * a;   /* mcmc.h:310 */
@@ -744,6 +773,30 @@ int mcmc_hip_set_state(mcmc_hip_ctx* c, const uint64_t* rng_state, const double*
     return 0;
 } MCMC_ABI_GUARD
 
+int mcmc_hip_get_scan_position(mcmc_hip_ctx* c, int64_t* out) try {
+    if (int r = check_ctx(c)) return r;
+    if (!c->haveChains) return fail(MCMC_HIP_ESTATE, "get_scan_position: call set_chains first");
+    if (!out) return fail(MCMC_HIP_EINVAL, "null output buffer");
+    *out = (int64_t)c->headCounter;
+    return 0;
+} MCMC_ABI_GUARD
+
+int mcmc_hip_set_region_state(mcmc_hip_ctx* c, int64_t scan_position, const double* region_stepsizes) try {
+    if (int r = check_ctx(c)) return r;
+    if (!c->haveChains) return fail(MCMC_HIP_ESTATE, "set_region_state: call set_chains first");
+    if (scan_position < 0) return fail(MCMC_HIP_EINVAL, "set_region_state: the scan position counts steps, it cannot be negative");
+    HIP_TRY(hipSetDevice(c->device));
+    if (region_stepsizes) {
+        const size_t cnt = (size_t)c->nChains * c->nRegions;
+        for (size_t i = 0; i < cnt; ++i)
+            if (!(region_stepsizes[i] > 0) || !std::isfinite(region_stepsizes[i]))
+                return fail(MCMC_HIP_EINVAL, "set_region_state: step size %zu is not a positive finite number", i);
+        if (int r = upload_field<double>(c, region_stepsizes, c->nRegions, c->S.stepsize)) return r;
+    }
+    c->headCounter = (long long)scan_position;
+    return 0;
+} MCMC_ABI_GUARD
+
 int mcmc_hip_step(mcmc_hip_ctx* c, int32_t n_steps, double beta, int32_t random_subspace) try {
     if (int r = check_ctx(c)) return r;
     if (!c->haveChains) return fail(MCMC_HIP_ESTATE, "step: call set_chains first");
@@ -1061,8 +1114,13 @@ static int with_external(mcmc_hip_ctx* c, int64_t n, const double* params, bool 
         if (e != hipSuccess) { rc = fail(MCMC_HIP_EHIP, "upload failed: %s", hipGetErrorString(e)); break; }
         const unsigned tb = 256, tg = (unsigned)((nP + tb - 1) / tb);
         hipLaunchKernelGGL(tile_in_kernel<double>, dim3(tg), dim3(tb), 0, c->stream, (const double*)stage.p, soa.p, (long long)n, dim, nP);
-        if (tmp.multi && R > 1)
+        e = hipGetLastError();
+        if (e != hipSuccess) { rc = fail(MCMC_HIP_EHIP, "tile_in launch failed: %s", hipGetErrorString(e)); break; }
+        if (tmp.multi && R > 1) {
             hipLaunchKernelGGL(mirror_betas_kernel, dim3(tg), dim3(tb), 0, c->stream, soa.p, nP, R, c->dimRegion, c->nB + c->cfg.n_disc);
+            e = hipGetLastError();
+            if (e != hipSuccess) { rc = fail(MCMC_HIP_EHIP, "mirror_betas launch failed: %s", hipGetErrorString(e)); break; }
+        }
         if (derive) {
             if (c->cfg.contract) rc = launch_chain_kernel(&tmp, derive_kernel<MCMC_T_DERIVE, true>, true, MCMC_T_DERIVE, tmp.M, tmp.S, (const double*)soa.p, res.p);
             else rc = launch_chain_kernel(&tmp, derive_kernel<MCMC_T_DERIVE, false>, true, MCMC_T_DERIVE, tmp.M, tmp.S, (const double*)soa.p, res.p);
@@ -1119,13 +1177,14 @@ int mcmc_hip_eval_static(mcmc_hip_ctx* c, int64_t n, const double* params_dev, d
     if (int r = check_ctx(c)) return r;
     if (!c->haveTables || !c->haveData) return fail(MCMC_HIP_ESTATE, "call set_tables and set_data first");
     if (n < 1 || !params_dev || !ll_out_dev) return fail(MCMC_HIP_EINVAL, "need n >= 1, device params and a device output buffer");
+    if (c->multi) return fail(MCMC_HIP_EINVAL, "eval_static: single-region contexts only");
     const int64_t nMax = mcmc_hip_eval_static_max(c);
     if (n > nMax)
         return fail(MCMC_HIP_EINVAL, "eval_static: %lld parameter vectors exceed the static scratch (%u bytes hold at most %lld "
                     "vectors of this model); use mcmc_hip_eval", (long long)n, (unsigned)MCMC_STATIC_SCRATCH_BYTES, (long long)nMax);
     if (!c->staticScratch) return fail(MCMC_HIP_ESTATE, "eval_static: no static scratch address for this device");
-    if (c->multi) return fail(MCMC_HIP_EINVAL, "eval_static: single-region contexts only");
     HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> busy(g_scratch_busy[c->device]);      /* until this call's kernels have finished */
     const long long nP = (n + MCMC_WAVE - 1) / MCMC_WAVE * MCMC_WAVE;
     const int dim = c->dim;
     /* carve this device's array: [soa | hn | he | d1s | res], each tile-major for nP lanes; the

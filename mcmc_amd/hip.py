@@ -21,10 +21,10 @@ OUT_CURVES = ["mildlyInfectious", "highlyInfectious", "incubating", "asymptomati
 # every symbol include/mcmc_hip.h declares
 SYMBOLS = [
     "mcmc_hip_last_error", "mcmc_hip_device_count", "mcmc_host_make_response_tables",
-    "mcmc_host_default_disease_params", "mcmc_host_perturb_ics", "mcmc_hip_create",
+    "mcmc_host_default_disease_params", "mcmc_host_perturb_ics", "mcmc_host_perturb_ics_from", "mcmc_hip_create",
     "mcmc_hip_destroy", "mcmc_hip_set_tables", "mcmc_hip_set_data", "mcmc_hip_set_precision", "mcmc_hip_set_chains",
     "mcmc_hip_set_state", "mcmc_hip_set_regions", "mcmc_hip_n_regions", "mcmc_hip_get_region_loglike",
-    "mcmc_hip_get_region_stepsizes",
+    "mcmc_hip_get_region_stepsizes", "mcmc_hip_get_scan_position", "mcmc_hip_set_region_state",
     "mcmc_hip_run", "mcmc_hip_step", "mcmc_hip_n_saved", "mcmc_hip_dim", "mcmc_hip_size",
     "mcmc_hip_n_chains", "mcmc_hip_get_params", "mcmc_hip_get_loglike", "mcmc_hip_get_stepsizes",
     "mcmc_hip_get_accept_counts", "mcmc_hip_get_rng_state", "mcmc_hip_get_loglikes",
@@ -77,6 +77,7 @@ def lib():
     L.mcmc_host_default_disease_params.argtypes = [C.POINTER(DiseaseParams)]
     L.mcmc_host_default_disease_params.restype = None
     L.mcmc_host_perturb_ics.argtypes = [dp, C.c_int32, C.c_int64, C.c_double, C.c_uint64, C.c_uint64, dp]
+    L.mcmc_host_perturb_ics_from.argtypes = [dp, C.c_int32, C.c_int64, C.c_int64, C.c_double, C.c_uint64, C.c_uint64, dp]
     L.mcmc_hip_create.argtypes = [C.POINTER(CovidConfig), C.c_int, C.POINTER(vp)]
     L.mcmc_hip_destroy.argtypes = [vp]
     L.mcmc_hip_set_tables.argtypes = [vp, dp, C.c_int32]
@@ -87,6 +88,8 @@ def lib():
     L.mcmc_hip_n_regions.argtypes = [vp]
     L.mcmc_hip_get_region_loglike.argtypes = [vp, dp]
     L.mcmc_hip_get_region_stepsizes.argtypes = [vp, dp]
+    L.mcmc_hip_get_scan_position.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.mcmc_hip_set_region_state.argtypes = [vp, C.c_int64, dp]
     L.mcmc_hip_set_state.argtypes = [vp, C.POINTER(C.c_uint64), dp, dp, C.POINTER(C.c_int32)]
     L.mcmc_hip_run.argtypes = [vp] + [C.c_int32] * 6
     L.mcmc_hip_step.argtypes = [vp, C.c_int32, C.c_double, C.c_int32]
@@ -149,10 +152,16 @@ def make_response_tables(disease_params: dict, n_traj=10_000_000, n_lag=500):
     return R
 
 
-def perturb_ics(x0, n_chains, a=0.01, initstate=0, initseq=0):
+def perturb_ics(x0, n_chains, a=0.01, initstate=0, initseq=0, first_chain=0):
+    """chains [first_chain, first_chain + n_chains) of ONE global sequence of starting points (chain i has
+    the same start on any sharding); first_chain > 0 jumps the generator ahead instead of drawing the
+    earlier chains"""
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     out = np.zeros((n_chains, x0.size), dtype=np.float64)
-    _check(lib().mcmc_host_perturb_ics(_dp(x0), x0.size, n_chains, a, initstate, initseq, _dp(out)))
+    if first_chain:
+        _check(lib().mcmc_host_perturb_ics_from(_dp(x0), x0.size, first_chain, n_chains, a, initstate, initseq, _dp(out)))
+    else:
+        _check(lib().mcmc_host_perturb_ics(_dp(x0), x0.size, n_chains, a, initstate, initseq, _dp(out)))
     return out
 
 
@@ -168,7 +177,8 @@ def toy_eval(kind, x, difficulty=1.0, device=0):
 
 
 def toy_run(kind, x0, n_samples, n_burnin, n_adjust, thinning, difficulty=1.0, target="plain", T=1.0, slope=0.0,
-            Tinit=1.0, stepsizes=1.0, chain_ids=None, first_chain_id=0, device=0, rng_state=None, mean_in=None):
+            Tinit=1.0, stepsizes=1.0, chain_ids=None, first_chain_id=0, device=0, rng_state=None, mean_in=None,
+            record=True):
     """MetropolisChain::run for n toy chains on the GPU (test.cpp:27-40 is kind='mylike1',
     one chain, id 0, x0 = (1,1,1), run(100000, 10, 500, 5)).  Returns a dict; `samples` and
     `mean` have n_out columns (MyLike1: position + its coordinate "max")."""
@@ -178,9 +188,9 @@ def toy_run(kind, x0, n_samples, n_burnin, n_adjust, thinning, difficulty=1.0, t
     assert dim == L.mcmc_hip_toy_dim(TOY[kind])
     ss = np.array(np.broadcast_to(stepsizes, (n,)), dtype=np.float64)
     ns = L.mcmc_hip_n_saved(n_samples, n_burnin, n_adjust, thinning)
-    ll = np.zeros((n, ns))
     n_out = L.mcmc_hip_toy_n_out(TOY[kind])
-    samples = np.zeros((n, ns, n_out))
+    ll = np.zeros((n, ns)) if record else None                 # record=False: end state, mean and accept counts only
+    samples = np.zeros((n, ns, n_out)) if record else None
     mean = np.zeros((n, n_out)) if mean_in is None else np.array(mean_in, dtype=np.float64, order="C").reshape(n, n_out)
     rng = None if rng_state is None else np.array(rng_state, dtype=np.uint64, order="C").reshape(n, 2)
     acc = np.zeros(n, dtype=np.int32)
@@ -270,6 +280,17 @@ class CovidSampler:
 
     def region_stepsizes(self):
         return self._get("get_region_stepsizes", (self.n_chains, self.n_regions))
+
+    def scan_position(self):
+        v = C.c_int64()
+        _check(lib().mcmc_hip_get_scan_position(self._h, C.byref(v)))
+        return v.value
+
+    def set_region_state(self, scan_position, region_stepsizes=None):
+        """mcmc_hip_set_region_state: the scan position and per-region step sizes of resumed multi-region chains"""
+        ss = None if region_stepsizes is None else np.ascontiguousarray(region_stepsizes, dtype=np.float64)
+        assert ss is None or ss.shape == (self.n_chains, self.n_regions)
+        _check(lib().mcmc_hip_set_region_state(self._h, scan_position, _dp(ss)))
 
     def set_chains(self, params, stepsizes=None, chain_ids=None, first_chain_id=1):
         params = np.ascontiguousarray(params, dtype=np.float64)

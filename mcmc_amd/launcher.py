@@ -12,6 +12,9 @@ import os
 import socket
 import subprocess
 import sys
+import time
+
+GRACE_S = 10.0          # what the surviving ranks get between SIGTERM and SIGKILL once one rank has failed
 
 
 def free_port():
@@ -32,23 +35,31 @@ def plan_launch(n_gpus, env):
         return None
     if n_gpus == 1:
         return None
-    port = str(free_port())
+    # the rendezvous port: the caller's MASTER_PORT if it set one (a probed "free" port can be taken by
+    # another process between the probe and rank 0's bind; a caller that knows its machine can fix it)
+    port = env.get("MASTER_PORT") or str(free_port())
+    # HSA_ENABLE_IPC_MODE_LEGACY=0 unless the caller chose otherwise: RCCL shares device buffers between the
+    # rank processes through IPC handles, and hosts whose driver only supports dmabuf IPC fail with
+    # `hipIpcGetMemHandle: invalid argument` under the legacy mode
     return [{"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_gpus), "LOCAL_WORLD_SIZE": str(n_gpus),
              "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port,
              "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")} for r in range(n_gpus)]
 
 
-def spawn_ranks(script, argv, overlays, env=None):
-    """Starts one child per overlay (python script argv...), waits for all; if one fails the others
-    are ended (by their own PIDs).  Returns the first non-zero exit code, or 0."""
+def spawn_ranks(script, argv, overlays, env=None, grace_s=GRACE_S):
+    """Starts one child per overlay (python script argv...), waits for all.  If one fails, the others get
+    SIGTERM, then `grace_s` seconds, then SIGKILL -- each by its own PID: a rank blocked in a rendezvous or a
+    collective whose partner is gone may never act on SIGTERM, and the launcher must still return.
+    Returns the first non-zero exit code, or 0."""
     env = dict(os.environ if env is None else env)
     procs = [subprocess.Popen([sys.executable, "-u", script] + list(argv), env={**env, **ov}) for ov in overlays]
     rc = 0
     pending = list(procs)
+    deadline = None
     while pending:
         for p in list(pending):
             try:
-                code = p.wait(timeout=0.5)
+                code = p.wait(timeout=0.2)
             except subprocess.TimeoutExpired:
                 continue
             pending.remove(p)
@@ -56,4 +67,9 @@ def spawn_ranks(script, argv, overlays, env=None):
                 rc = code
                 for q in pending:
                     q.terminate()
+                deadline = time.monotonic() + grace_s
+        if deadline is not None and pending and time.monotonic() > deadline:
+            for q in pending:
+                q.kill()
+            deadline = None
     return rc

@@ -46,7 +46,44 @@ def test_single_gpu_line_has_the_whole_contract():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > cb["faithful"]["value"] > 0
     assert d["strict"]["fp_contract"] == "strict" and 0 < d["strict"]["value"] < d["value"]
     assert d["fp32_fast_mode"]["peak"] == 157.3 and d["fp32_fast_mode"]["value"] > 0
-    assert "converged" in d["ess"] and (d["ess"]["converged"] or "ess_per_s" not in d["ess"])
+    assert "converged" in d["ess"] and (d["ess"]["converged"] or "gpu_ess_per_s" not in d["ess"])
+    assert set(d["ess"]["ess_per_step_within_chain"]) == {"betaMild", "betaHigh", "delay"}
+    assert d["config"]["occupancy"] == {"waves_per_gpu": 64, "simds_per_gpu": 1024, "frac": 64 / 1024}
+    assert rf["frac_executed"] == rf["executed"]["frac"] and "algorithmic" in rf["frac_counts"]
+    # the metric's second half on targets where the reference's sampler mixes (BASELINE configs[0])
+    toy = d["ess_toy"]
+    assert toy["mylike1"]["converged"] and toy["mylike1"]["cpu_chains_bit_identical_to_gpu"]
+    assert toy["rosenbrock"]["cpu_chains_bit_identical_to_gpu"]
+    for leg in toy.values():
+        assert leg["gpu"]["ess_per_s"] > leg["cpu"]["ess_per_s"] > 0 and leg["gpu"]["chains"] == 65536
+
+
+def test_config_c1_line_names_its_occupancy():
+    """BASELINE configs[1]: 1 024 chains x 200 days on one GPU -- 16 waves for 1 024 SIMDs."""
+    d = _bench("--config", "c1", "--steps", "16", "--warmup", "16", "--adjust", "2", "--ess-chains", "0",
+               "--no-fast-leg", "--no-strict-leg", "--no-toy-ess")
+    c = d["config"]
+    assert c["chains_per_gpu"] == 1024 and c["n_data"] == 200 and c["size"] == 300 and c["dim"] == 193
+    assert "configs[1]" in c["workload"] and c["occupancy"]["waves_per_gpu"] == 16
+    assert abs(c["occupancy"]["frac"] - 16 / 1024) < 1e-12
+    assert d["roofline"]["traffic"] is None and "200-day" in d["cpu_baseline"]["sample"]
+
+
+def test_total_chains_is_strong_scaling_and_does_not_change_the_chains():
+    """--total-chains splits a FIXED total by contiguous chain-id range: one rank and two ranks (rehearsed on one
+    card over gloo) run the same 4 096 chains -- same starts (jumped generator), same streams -- so the
+    cross-chain diagnostics of the two jobs agree to summation order."""
+    common = ("--total-chains", "4096", "--steps", "16", "--warmup", "16", "--adjust", "2", "--no-cpu-baseline",
+              "--ess-chains", "0", "--no-fast-leg", "--no-strict-leg", "--no-toy-ess")
+    one = _bench(*common)
+    two = _bench("--gpus", "2", "--backend", "gloo", "--device", "0", *common)
+    assert one["scaling"] == two["scaling"] == "strong"
+    assert one["config"]["chains_total"] == two["config"]["chains_total"] == 4096
+    assert one["config"]["chains_per_gpu"] == 4096 and two["config"]["chains_per_gpu"] == 2048 and two["n_gpus"] == 2
+    d1, d2 = one["diagnostics"], two["diagnostics"]
+    assert d1["chains"] == d2["chains"] == 4096 and d1["acceptance_timed_steps"] == d2["acceptance_timed_steps"]
+    for k in ("loglike_mean_sd", "betaMild_mean_sd", "betaHigh_mean_sd", "delay_mean_sd"):
+        assert abs(d1[k][0] - d2[k][0]) <= 1e-12 * abs(d1[k][0]) and abs(d1[k][1] - d2[k][1]) <= 1e-9 * abs(d1[k][1]), k
 
 
 def test_gpus_flag_launches_its_ranks():

@@ -210,3 +210,42 @@ def test_bench_gpus_flag_spawns_the_ranks_and_reports_failure(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                            capture_output=True, text=True, timeout=600)
         assert r.returncode != 0 and "no GPU visible" in (r.stderr + r.stdout) and "{" not in r.stdout
+
+
+def test_perturb_ics_jump_ahead_equals_the_sliced_sequence(R11):
+    """A rank's starting points are chains [first, first + n) of ONE global pcg32(0, 0) sequence; jumping the
+    generator first * dim draws ahead (O(log) steps) must give exactly what drawing from the start and slicing
+    gives -- so chain i starts at the same point on any sharding, and set-up is O(own chains) per rank."""
+    cfg = make_cfg(40, R11, max_delay=12, n_predict=5, fix_behavior_in_advance=5, initial_delay=7.0)
+    x0 = CC.initial_params(cfg)
+    whole = H.perturb_ics(x0, 300, 0.01)
+    for first, n in [(1, 5), (64, 64), (137, 163), (299, 1), (0, 7)]:
+        assert np.array_equal(H.perturb_ics(x0, n, 0.01, first_chain=first), whole[first:first + n])
+    # far into the sequence (rank 7 of 8 x 65536 chains x 358 coordinates: 1.6e8 draws) against the oracle's
+    # own generator stepped that far is too slow for a unit test; check the jump's group property instead:
+    # jumping a + b equals the chain a + b of a sequence that itself was started by a jump
+    big = 7 * 65536
+    a = H.perturb_ics(x0, 3, 0.01, first_chain=big)
+    b = H.perturb_ics(x0, 2, 0.01, first_chain=big + 1)
+    assert np.array_equal(a[1:], b)
+    # other seeds of the sequence
+    assert np.array_equal(H.perturb_ics(x0, 4, 0.05, initstate=3, initseq=9, first_chain=11),
+                          H.perturb_ics(x0, 15, 0.05, initstate=3, initseq=9)[11:])
+    out = np.zeros((1, x0.size))
+    assert H.lib().mcmc_host_perturb_ics_from(None, x0.size, 0, 1, 0.01, 0, 0, out.ctypes.data_as(C.POINTER(C.c_double))) == -1
+
+
+def test_launcher_ends_ranks_that_ignore_sigterm_and_honours_master_port(tmp_path):
+    """One rank fails; the other ignores SIGTERM (as a rank stuck in a collective may): the launcher kills it by
+    PID after the grace period and returns the failing code instead of hanging.  A caller's MASTER_PORT is kept."""
+    import time
+    from mcmc_amd import launcher as LA
+    script = tmp_path / "rank.py"
+    script.write_text("import os, signal, sys, time\n"
+                      "if os.environ['RANK'] == '0':\n    time.sleep(0.5); sys.exit(5)\n"
+                      "signal.signal(signal.SIGTERM, signal.SIG_IGN)\ntime.sleep(120)\n")
+    ov = LA.plan_launch(2, {"MASTER_PORT": "29544"})
+    assert {o["MASTER_PORT"] for o in ov} == {"29544"}
+    t0 = time.monotonic()
+    assert LA.spawn_ranks(str(script), [], ov, grace_s=1.0) == 5
+    assert time.monotonic() - t0 < 30
