@@ -253,7 +253,7 @@ def test_run_with_recording_at_65536_chains(R11, R10):
     cfg = make_cfg(365, R11, contract=1)
     n = 65536
     xs = H.perturb_ics(CC.initial_params(cfg), n, 0.01)
-    sched = (7, 1, 1, 2)                       # 1 adjust group (20 steps) + 7 steps; 4 points recorded
+    sched = (8, 1, 1, 2)                       # 1 adjust group (20 steps) + 8 steps; points recorded at i = 2, 4, 6, 8
     big = H.CovidSampler(cfg, R10)
     big.set_chains(xs, first_chain_id=1)
     big.run(*sched, record_samples=True, compute_mean=True)
