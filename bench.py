@@ -48,7 +48,7 @@ STEPS_PER_LAUNCH = 16               # MCMC_STEPS_PER_LAUNCH of the library
 BETA_MILD, BETA_HIGH = 0.8, 2.5
 
 
-def build_workload(device, n_chains, first_chain_id, contract, n_data=N_DATA, precision="f64"):
+def build_workload(device, n_chains, first_chain_id, contract, n_data=N_DATA, precision="f64", spread=0.01):
     """Synthetic inputs per SURVEY 8(d): response table by the host precompute, counts by the
     forward model at the initial parameters, sigma by the notebook's recipe, chains = initial
     parameters perturbed by +-1 % (pcg32(0,0)), chain ids first_chain_id.."""
@@ -66,13 +66,13 @@ def build_workload(device, n_chains, first_chain_id, contract, n_data=N_DATA, pr
     x0 = CC.initial_params(cfg)
     # one global IC stream so that chain i has the same start on any sharding; a rank jumps the generator to
     # its first chain instead of drawing everybody else's (tests/test_host_cpu.py: jumped == sliced)
-    xs = H.perturb_ics(x0, n_chains, 0.01, first_chain=first_chain_id - 1)
+    xs = H.perturb_ics(x0, n_chains, spread, first_chain=first_chain_id - 1)
     sampler = H.CovidSampler(cfg, R, device, precision=precision)
     sampler.set_chains(xs, first_chain_id=first_chain_id)
     return cfg, R, xs, sampler
 
 
-def build_region_workload(device, n_chains, first_chain_id, contract, n_regions, n_data):
+def build_region_workload(device, n_chains, first_chain_id, contract, n_regions, n_data, spread=0.01):
     """BASELINE.json configs[4] (extension, include/mcmc_hip.h at mcmc_hip_set_regions): n_regions regions per
     chain over a long horizon (n_data days; maxDelay 40 + nPredict 60 on top: beyond the 500-day response
     table), each a complete DiseaseSpread block -- three behaviour nodes, one breakpoint value, its delay --
@@ -92,7 +92,7 @@ def build_region_workload(device, n_chains, first_chain_id, contract, n_regions,
     cfgs = [CC.synthetic_config(n_data, forward, pop_size=int(6e7 / (1 + 0.25 * (r % 8))), cap0=7500.0 / (1 + r % 5),
                                 cap_incr_rate=100.0 - r % 50, **kw) for r in range(n_regions)]
     x0 = np.concatenate([CC.initial_params(c) for c in cfgs])
-    xs = H.perturb_ics(x0, n_chains, 0.01, first_chain=first_chain_id - 1)
+    xs = H.perturb_ics(x0, n_chains, spread, first_chain=first_chain_id - 1)
     sampler = H.CovidSampler(cfgs[0], R, device)
     sampler.set_regions(cfgs)
     sampler.set_chains(xs, first_chain_id=first_chain_id)
@@ -283,6 +283,9 @@ def main():
     ap.add_argument("--contract", type=int, default=int(os.environ.get("MCMC_BENCH_CONTRACT", "1")))
     ap.add_argument("--adjust", type=int, default=int(os.environ.get("MCMC_BENCH_ADJUST", "25")),
                     help="adjust-phase iterations (20 MH steps each, mcmc.h:1083-1119) run untimed before the warm-up")
+    ap.add_argument("--start-spread", type=float, default=None,
+                    help="relative spread of the chains' starting points around the generating parameters "
+                         "(State::perturb's rule, mcmc.h:306-314); default 0.01 as SURVEY 8d, 0.001 with --regions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-leg", action="store_true", help="skip the FP32 fast-mode leg (N=1 only)")
     ap.add_argument("--no-strict-leg", action="store_true", help="skip the strict (no FMA contraction) leg (N=1 only)")
@@ -314,6 +317,10 @@ def main():
         args.chains_per_gpu = CHAINS_PER_GPU
     if args.n_data is None:
         args.n_data = N_DATA
+    if args.start_spread is None:
+        # a region's 600-day epidemic answers a 1 % change of the betas with a log-likelihood of -5e7: started
+        # there the timed steps are a wild transient (acceptance 0.17); 0.1 % starts the chains near the mode
+        args.start_spread = 0.001 if args.regions else 0.01
 
     # ---- one process per GPU: become the launcher if this is a plain `--gpus N` call (nothing in
     # this process has touched HIP or torch yet) ----
@@ -358,11 +365,11 @@ def main():
         if args.ladder or args.precision != "f64":
             raise SystemExit("bench.py: --regions runs without --ladder, in f64")
         n_data = args.region_days
-        cfgs, R, xs, s = build_region_workload(device, n_chains, first_id, args.contract, args.regions, n_data)
+        cfgs, R, xs, s = build_region_workload(device, n_chains, first_id, args.contract, args.regions, n_data, args.start_spread)
         cfg = dict(cfgs[0])
         cfg["dim"] = s.dim
     else:
-        cfg, R, xs, s = build_workload(device, n_chains, first_id, args.contract, n_data=n_data, precision=args.precision)
+        cfg, R, xs, s = build_workload(device, n_chains, first_id, args.contract, n_data=n_data, precision=args.precision, spread=args.start_spread)
     fast_main = args.precision != "f64"
     peak = PEAK_FP32_VECTOR_TFLOPS if fast_main else PEAK_FP64_VECTOR_TFLOPS
 
@@ -464,7 +471,7 @@ def main():
                                               "in which the compiler contracts project()'s `dest[d+k] += n*cumsum` (covid.h:384) "
                                               "into one fused multiply-add; every other expression is a separate mul / add") if args.contract
                                              else "the C++ source semantics: every projection term a multiply, then an add",
-                       "adjust_iterations_before_timing": args.adjust,
+                       "adjust_iterations_before_timing": args.adjust, "start_spread": args.start_spread,
                        **({"ladder": {"temperatures": args.ladder, "t_max": args.ladder_tmax,
                                       "swap_every": args.swap_every}} if args.ladder else {}),
                        "parallelism": f"chain-shard x{world}"},

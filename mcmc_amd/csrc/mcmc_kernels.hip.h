@@ -539,19 +539,26 @@ __device__ __forceinline__ void lag_chunk_e(double (&acc)[A_NPOS][T], double (&W
 #ifndef MCMC_E_SCHEDBAR
 #define MCMC_E_SCHEDBAR 1
 #endif
+#ifndef MCMC_PLAIN_DRAIN
+#define MCMC_PLAIN_DRAIN 1
+#endif
 #ifndef MCMC_DPP_ROWS
 #define MCMC_DPP_ROWS 1
 #endif
+/* which block sizes take their rows 0..T-1 across the lanes: even T (a register pair holds two rows) */
+#define MCMC_ROWS_IN_LANES(T, FUSE) ((FUSE) && ((T) % 2 == 0) && (T) >= 8 && MCMC_DPP_ROWS)   /* the derive kernel (T = 4) keeps the LDS rows: a cross-check of the two forms */
+template <int T>
 struct RowRegs {
-    double pos[4];      /* rows 0..7 of Rpos, two rows per pair                             */
-    double neg[2];      /* rows 0..7 of Rneg, four rows per pair: lane 4*(d&3)+c             */
+    double pos[(T + 1) / 2];      /* rows 0..T-1 of Rpos, two rows per pair                          */
+    double neg[(T + 3) / 4];      /* rows 0..T-1 of Rneg, four rows per pair: lane 4*(d&3)+c          */
 };
-__device__ __forceinline__ RowRegs load_row_regs(const LdsView& lds, unsigned lane) {
-    RowRegs R;
+template <int T>
+__device__ __forceinline__ RowRegs<T> load_row_regs(const LdsView& lds, unsigned lane) {
+    RowRegs<T> R;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) R.pos[g] = lds.Rpos[(2 * g + ((lane >> 3) & 1)) * 8 + (lane & 7)];
+    for (int g = 0; g < (T + 1) / 2; ++g) R.pos[g] = lds.Rpos[(2 * g + ((lane >> 3) & 1)) * 8 + (lane & 7)];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) R.neg[h] = lds.Rneg[(4 * h + ((lane >> 2) & 3)) * 4 + (lane & 3)];
+    for (int h = 0; h < (T + 3) / 4; ++h) R.neg[h] = lds.Rneg[(4 * h + ((lane >> 2) & 3)) * 4 + (lane & 3)];
     return R;
 }
 #define MCMC_DPP_FMAC(D, LANE) "v_fmac_f64_dpp " D ", %[row], %[nk] row_newbcast:" #LANE " row_mask:0xf bank_mask:0xf\n\t"
@@ -603,7 +610,7 @@ __device__ __forceinline__ void dpp_neg3(double (&acc)[A_NPOS][T], int tt, doubl
 #undef MCMC_DPP_NEG
 }
 template <int T>
-__device__ __forceinline__ void dpp_neg3_at(double (&acc)[A_NPOS][T], int tt, int d, const RowRegs& RR, double ek, double nek) {
+__device__ __forceinline__ void dpp_neg3_at(double (&acc)[A_NPOS][T], int tt, int d, const RowRegs<T>& RR, double ek, double nek) {
     const double negv = RR.neg[d >> 2];
     switch (d & 3) {
         case 0: dpp_neg3<T, 0>(acc, tt, negv, ek, nek); break;
@@ -617,8 +624,8 @@ __device__ __forceinline__ void dpp_neg3_at(double (&acc)[A_NPOS][T], int tt, in
 template <int T, bool FUSE, bool WITH_E>
 __device__ __forceinline__ void lag_tail(double (&acc)[A_NPOS][T], const double (&W)[T],
                                          const double* Rpos, const double* Rneg, const double* he_k0_u,
-                                         unsigned lane, const RowRegs& RR) {
-    if constexpr (FUSE && T == 8 && MCMC_DPP_ROWS) {
+                                         unsigned lane, const RowRegs<T>& RR) {
+    if constexpr (MCMC_ROWS_IN_LANES(T, FUSE)) {
         double ek[WITH_E ? T - 1 : 1];
         if constexpr (WITH_E) {
 #pragma unroll
@@ -807,11 +814,22 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
              * The three runs are three pieces of straight-line code, not one loop over a run index: as a
              * loop, the 56 accumulators and both windows went through a register-to-register copy at
              * every run's entry (~230 instructions, up to three times per block). */
-            auto run_plain = [&](int nch) {
+            auto run_plain = [&](int nch, bool firstRun) {
                 pc.count(PH_NCHUNK, nch);
                 unsigned laneL = lane;
 #if MCMC_LANE_LAUNDER
                 asm volatile("" : "+v"(laneL));
+#endif
+                /* The block's first run is entered with the previous block's phase-B STORES still pending as far
+                 * as the compiler can tell (they were issued after this block's window loads).  gfx9 counts loads
+                 * and stores in one vmcnt and they may complete out of order with respect to each other, so with
+                 * both kinds pending every wait for a window register becomes vmcnt(0) -- and, the loop header
+                 * merging that state into every iteration, a full drain of the window prefetch at the top of
+                 * EVERY iteration of this loop (found in round 3: tools/isa_guard.py only looked at the last of
+                 * the two plain loops).  In real time those stores and loads finished during phase B: draining
+                 * here, once per block, costs nothing and lets the loop wait with vmcnt(T + 1). */
+#if MCMC_PLAIN_DRAIN
+                if (firstRun && nch >= 2) __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0) */
 #endif
 #pragma unroll 1
                 for (; nch >= 2; nch -= 2) {
@@ -829,7 +847,7 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                 }
                 pc.stamp(PH_CHUNKS);
             };
-            run_plain(cLo - c0r);
+            run_plain(cLo - c0r, true);
             {
                 int nch = cHi - cLo + 1;
                 pc.count(PH_NCHUNK_E, nch);
@@ -873,13 +891,13 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                 }
                 pc.stamp(PH_CHUNKS_E);
             }
-            run_plain(bRun - 1 - cHi);
+            run_plain(bRun - 1 - cHi, false);
             /* what phase B needs from memory is requested before the tail's 7*T*(T-1)/2
              * multiply-adds: behaviour values and piecewise factors of the block's days.
              * Rows 0..T-1 across the lanes, for the tail and phase B of this block (re-read per
              * block: six LDS reads, and the registers stay free during the lag loops) */
-            RowRegs RR;
-            if constexpr (FUSE && T == 8 && MCMC_DPP_ROWS) RR = load_row_regs(lds, lane);
+            RowRegs<T> RR;
+            if constexpr (MCMC_ROWS_IN_LANES(T, FUSE)) RR = load_row_regs<T>(lds, lane);
             double pcfv[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
@@ -921,7 +939,7 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                  * the rows 0..T-1 are re-read from LDS every day (the opaque zero keeps the
                  * compiler from parking all of them in AccVGPRs, which costs two register
                  * moves per multiply-add) */
-                if constexpr (FUSE && T == 8 && MCMC_DPP_ROWS) {
+                if constexpr (MCMC_ROWS_IN_LANES(T, FUSE)) {
 #pragma unroll
                     for (int d = 0; d < T - t; d += 2) {
                         if (d + 1 < T - t) dpp_row14<T>(acc, t + d, RR.pos[d >> 1], ncur);
@@ -954,7 +972,7 @@ __device__ __forceinline__ double eval_model(const DevModel& M, const LdsView& l
                     keHi = max(keHi, i);
                     pc.count(PH_EDAYS, 1);
                     const double ne = -e;
-                    if constexpr (FUSE && T == 8 && MCMC_DPP_ROWS) {
+                    if constexpr (MCMC_ROWS_IN_LANES(T, FUSE)) {
 #pragma unroll
                         for (int tt = t; tt < T; ++tt) dpp_neg3_at<T>(acc, tt, tt - t, RR, e, ne);
                     } else {

@@ -19,7 +19,7 @@ def test_lag_loops_keep_their_prefetch_in_flight(tmp_path):
     r = json.loads(out.strip().splitlines()[-1])
     plain, eterm = r["plain_loop"], r["eterm_loop"]
     # two chunks of 8 lag steps per iteration: 56 (88) multiply-adds per step plus <= 7 (12) others
-    assert plain["ops"] == 896 and plain["instructions"] <= 1010
+    assert plain["ops"] == 896 and plain["instructions"] <= 1010 and plain["instances"] == 2     # both runs of a block
     assert eterm["ops"] == 1408 and eterm["instructions"] <= 1600
     assert plain["scratch"] == 0 and eterm["scratch"] == 0
     # the history window is refilled two chunks ahead: waits inside the loops must leave at

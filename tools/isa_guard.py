@@ -43,9 +43,20 @@ def analyse(workdir):
             if name is None or len(ins) < 500:
                 continue
             waits = [int(x) for t in ins for x in re.findall(r"vmcnt\((\d+)\)", t)]
-            out[name] = {"instructions": len(ins), "ops": fma, "scratch": sum("scratch" in t for t in ins),
+            # a kernel holds the plain loop twice (the runs before and after the chunks with e-terms): keep the
+            # WORSE figure of each kind, so that no instance escapes the guard
+            cur_stats = {"instructions": len(ins), "ops": fma, "scratch": sum("scratch" in t for t in ins),
                          "sgpr_spill_moves": sum(t.startswith(("v_readlane", "v_writelane")) for t in ins),
-                         "min_vmcnt": min(waits) if waits else None}
+                         "min_vmcnt": min(waits) if waits else None, "instances": 1}
+            if name in out:
+                prev = out[name]
+                cur_stats = {"instructions": max(prev["instructions"], cur_stats["instructions"]), "ops": fma,
+                             "scratch": max(prev["scratch"], cur_stats["scratch"]),
+                             "sgpr_spill_moves": max(prev["sgpr_spill_moves"], cur_stats["sgpr_spill_moves"]),
+                             "min_vmcnt": min(x for x in (prev["min_vmcnt"], cur_stats["min_vmcnt"]) if x is not None)
+                             if (prev["min_vmcnt"] is not None or cur_stats["min_vmcnt"] is not None) else None,
+                             "instances": prev["instances"] + 1}
+            out[name] = cur_stats
         if sym.endswith("Li0ELb0EE"):
             m0 = m
     m = m0

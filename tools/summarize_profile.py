@@ -34,8 +34,9 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.
         agg[k] += [x for _, x in v[-2:]]
 mean = {k: sum(v) / len(v) for k, v in agg.items()}
 with open(os.path.join(dst, f"{tag}_pmc_summary.txt"), "w") as o:
-    o.write("rocprofv3 --pmc passes (one run per pass) of `python3 bench.py --no-cpu-baseline --ess-chains 0 --steps 16 --warmup 16`;\n"
-            "mh_step_kernel, mean per launch over the last two launches (adapted regime; 16 MH steps x 65536 chains, 1024 waves)\n")
+    o.write("rocprofv3 --pmc passes (one run per pass) of `python3 bench.py --no-cpu-baseline --ess-chains 0 ... --steps 16 --warmup 16`;\n"
+            f"mh_step_kernel, mean per launch over the last two launches (adapted regime; 16 MH steps x {bench['config']['chains_per_gpu']} chains)\n"
+            f"workload: {bench['config']['workload']}\n")
     o.write(f"arithmetic of this run: {bench['dtype']}\n")
     o.write(trace_note)
     for k in sorted(mean):
@@ -48,7 +49,8 @@ with open(os.path.join(dst, f"{tag}_pmc_summary.txt"), "w") as o:
         o.write(f"HBM-side bytes per launch: fetch {fetch:.4g} (FETCH_SIZE KB x 1024 x 2, gfx950 correction) + write {write:.4g}\n")
         json.dump({"hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "tag": tag,
                    "chains": bench["config"]["chains_per_gpu"], "steps_per_launch": 16,
-                   "note": "FETCH_SIZE x2 (gfx950 under-count of wide coalesced reads) + WRITE_SIZE, per mh_step_kernel launch of 16 steps x 65536 chains"},
+                   "note": f"FETCH_SIZE x2 (gfx950 under-count of wide coalesced reads) + WRITE_SIZE, per mh_step_kernel launch of 16 steps x {bench['config']['chains_per_gpu']} chains"},
                   open(os.path.join(os.path.dirname(dst.rstrip('/')),
-                                    "traffic_fast_mode.json" if "fast" in tag else "traffic_latest.json"), "w"))
+                                    "traffic_fast_mode.json" if "fast" in tag else
+                                    "traffic_regions.json" if bench["config"].get("regions") else "traffic_latest.json"), "w"))
 print(open(os.path.join(dst, f"{tag}_pmc_summary.txt")).read())
