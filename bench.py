@@ -203,30 +203,43 @@ def toy_ess_leg(device, n_chains, threads):
     from oracle import oracle as O
     legs = {}
     n_rec = min(4096, n_chains)
-    # name, x0, (nSamples, nBurnin, nAdjust, thinning), difficulty, scalars of the ESS
-    for name, x0, sched, diff, k_use in [("mylike1", [1.0, 1.0, 1.0], (10000, 2000, 500, 5), 1.0, 3),
-                                          ("rosenbrock", [1.0, 1.0], (60000, 20000, 500, 20), 100.0, 2)]:
+    rs = np.random.default_rng(11)
+    # Rosenbrock: a random walk explores the curved ridge slowly, so its chains start from EXACT draws of the target
+    # (x ~ N(1, 10), y | x ~ N(x^2, 10 / difficulty)) and are stationary from the first step; MyLike1 starts every
+    # chain at (1, 1, 1) like test.cpp:36-38 and discards a burn-in
+    xr = 1 + np.sqrt(10.0) * rs.standard_normal(n_chains)
+    X_ros = np.stack([xr, xr ** 2 + np.sqrt(0.1) * rs.standard_normal(n_chains)], axis=1)
+    # name, starts, (nSamples, nBurnin, nAdjust, thinning), difficulty, scalars of the ESS
+    for name, X, sched, diff, k_use in [("mylike1", np.ones((n_chains, 3)), (10000, 2000, 500, 5), 1.0, 3),
+                                         ("rosenbrock", X_ros, (60000, 20000, 500, 20), 100.0, 2)]:
         ns, nb, na, th = sched
         steps_per_chain = 20 * na + ns
-        X = np.tile(np.array(x0), (n_chains, 1))
         H.toy_run(name, X[:64], 10, 0, 1, 1, difficulty=diff, first_chain_id=1, device=device, record=False)   # module load
-        t0 = time.perf_counter()
-        H.toy_run(name, X, ns, nb, na, th, difficulty=diff, first_chain_id=1, device=device, record=False)
-        gpu_wall = time.perf_counter() - t0
+        gpu_wall = 1e30
+        for _ in range(3):                                                   # best of three: the runs are milliseconds
+            t0 = time.perf_counter()
+            H.toy_run(name, X, ns, nb, na, th, difficulty=diff, first_chain_id=1, device=device, record=False)
+            gpu_wall = min(gpu_wall, time.perf_counter() - t0)
         rec = H.toy_run(name, X[:n_rec], ns, nb, na, th, difficulty=diff, first_chain_id=1, device=device)
         pts = rec["samples"][:, :, :k_use]                                   # [n_rec][n_saved][k]
         n_saved = pts.shape[1]
         ess = np.array([ess_geyer(pts[:, :, j]).mean() for j in range(k_use)])   # per chain
         rhat, _ = rhat_ess(moment_sums(pts), k_use, n_saved)
-        # CPU: the oracle's run of the same schedule, one chain per call, `threads` at a time
-        n_cpu = 4 * threads
+        # CPU: the oracle's run of the same schedule, one chain per call, `threads` at a time; the chain count is
+        # sized so that the timed sample lasts about two seconds
         fn = {"mylike1": lambda cid: O.mylike1_run(cid, ns, nb, na, th),
-              "rosenbrock": lambda cid: O.rosenbrock_run(diff, 1.0, cid, x0, ns, nb, na, th)}[name]
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(threads) as ex:
-            cpu = list(ex.map(fn, range(1, n_cpu + 1)))
-        cpu_wall = time.perf_counter() - t0
-        same = all(np.array_equal(cpu[c][1][:, :k_use], pts[c]) for c in range(min(n_cpu, n_rec)))
+              "rosenbrock": lambda cid: O.rosenbrock_run(diff, 1.0, cid, X[cid - 1], ns, nb, na, th)}[name]
+
+        def cpu_run(n_cpu):
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(threads) as ex:
+                res = list(ex.map(fn, range(1, n_cpu + 1)))
+            return res, time.perf_counter() - t0
+        cpu, cpu_wall = cpu_run(4 * threads)
+        n_cpu = int(min(n_chains, max(4 * threads, 4 * threads * 2.0 / max(cpu_wall, 1e-4))))
+        if n_cpu > 4 * threads:
+            cpu, cpu_wall = cpu_run(n_cpu)
+        same = all(np.array_equal(cpu[c][1][:, :k_use], pts[c]) for c in range(min(n_cpu, n_rec, 256)))
         worst = float(ess.min())
         legs[name] = {"converged": bool(np.all(np.isfinite(rhat)) and float(np.max(rhat)) < 1.1),
                       "rhat_max": float(np.max(rhat)), "ess_per_chain_worst_coordinate": worst,
@@ -235,10 +248,11 @@ def toy_ess_leg(device, n_chains, threads):
                               "ess_per_s": worst * n_chains / gpu_wall},
                       "cpu": {"chains": n_cpu, "threads": threads, "wall_s": cpu_wall,
                               "steps_per_s": n_cpu * steps_per_chain / cpu_wall, "ess_per_s": worst * n_cpu / cpu_wall},
-                      "gpu_over_cpu_ess_per_s": (worst * n_chains / gpu_wall) / (worst * n_cpu / cpu_wall),
+                      "gpu_over_cpu_ess_per_s": (n_chains / gpu_wall) / (n_cpu / cpu_wall),
                       "cpu_chains_bit_identical_to_gpu": bool(same),
                       "schedule": f"run({ns}, {nb}, {na}, {th}): {steps_per_chain} MH steps per chain, {n_saved} recorded points; "
-                                  f"ESS from the first {n_rec} chains"}
+                                  f"ESS (Geyer, per chain, worst coordinate, mean over chains) from the first {n_rec} chains; "
+                                  "GPU wall = best of three whole mcmc_hip_toy_run calls (upload, one launch, download of the end state)"}
     return legs
 
 

@@ -161,6 +161,24 @@ int mcmc_hip_set_region_state(mcmc_hip_ctx* ctx, int64_t scan_position, const do
 #define MCMC_HIP_PRECISION_F32_PACKED 2   /* its first form, packed FP32 vector multiply-adds; kept for comparison */
 int mcmc_hip_set_precision(mcmc_hip_ctx* ctx, int32_t mode);
 
+/* How the chains are laid onto the GPU by the step kernels.  NO COUNTERPART IN THE REFERENCE (one TBB task per
+ * chain, mcmc.h:1494-1508) and no effect on any result: both mappings execute the same operations in the same
+ * order and give the same bits (tests/test_gpu_wave_mapping.py).
+ *   LANE  one chain per lane, 64 chains per wavefront in lockstep: north_star's mapping, the one that fills the
+ *         chip from about 16 k chains on.
+ *   WAVE  one chain per WAVEFRONT (mcmc_wave_kernel.hip.h): a block of 16 days x 7 compartments is spread over
+ *         the wave's lanes and the FP64 matrix instruction; a chain's state lives in LDS for the length of a
+ *         launch.  For small ensembles -- BASELINE.json configs[1]'s 1 024 chains are 16 wavefronts under LANE
+ *         and 1 024 under WAVE.  Needs cfg.contract = 1, the double-precision mode, the single-region State and
+ *         a series that fits a wave's LDS slice (about 470 data days); set_mapping(WAVE) fails otherwise.
+ *   AUTO  (default) WAVE where possible for ensembles of at most 16 384 chains, else LANE.
+ * May be called at any time; it takes effect from the next launch.  get_mapping: what the next launch uses. */
+#define MCMC_HIP_MAPPING_AUTO 0
+#define MCMC_HIP_MAPPING_LANE 1
+#define MCMC_HIP_MAPPING_WAVE 2
+int mcmc_hip_set_mapping(mcmc_hip_ctx* ctx, int32_t mapping);
+int32_t mcmc_hip_get_mapping(const mcmc_hip_ctx* ctx);
+
 /* Replaces ChainManager's per-chain setup loop (mcmc.h:1517-1532): n chains, chain i has
  * RNG pcg32(0, chain_ids[i]) (mcmc.h:999,1527) and parameters params[i*dim .. i*dim+dim)
  * in the reference's coords order: behavior[nB], discontinuousVals[nDisc], betaMild,

@@ -8,6 +8,7 @@
  */
 #include "mcmc_hip.h"
 #include "mcmc_kernels.hip.h"
+#include "mcmc_wave_kernel.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -25,6 +26,9 @@
 #endif
 #ifndef MCMC_STEPS_PER_LAUNCH
 #define MCMC_STEPS_PER_LAUNCH 16   /* MH steps one mh_step_kernel launch advances every chain by */
+#endif
+#ifndef MCMC_WAVE_AUTO_MAX
+#define MCMC_WAVE_AUTO_MAX 16384   /* MCMC_HIP_MAPPING_AUTO: ensembles up to this many chains take one chain per wavefront */
 #endif
 #ifndef MCMC_T_DERIVE
 #define MCMC_T_DERIVE 4    /* the derive kernel is not a hot path: small block, short compile */
@@ -112,6 +116,8 @@ struct mcmc_hip_ctx {
     DevBuf<double> dRpos, dRneg, dCapacity, dDeaths, dSigma2;
     DevBuf<float> dRF;                  /* fast mode: float tables [size + 3*MCMC_TF][8] and [..][4] */
     int precision = MCMC_HIP_PRECISION_F64;
+    int mapping = MCMC_HIP_MAPPING_AUTO;   /* what the caller asked for */
+    bool useWave = false;                  /* what the step launches do: decided in set_chains / set_mapping */
     DevBuf<int> dSeg;
     /* chain state */
     DevBuf<double> dParams, dLL, dStepsize, dHn, dHe, dD1s, dMean, dRecLL, dRecSamples;
@@ -313,8 +319,36 @@ int run_eval_current(mcmc_hip_ctx* c) {
     return launch_chain_kernel(c, eval_kernel<MCMC_T, false>, false, MCMC_T, c->M, c->S, (const double*)c->S.params, c->S.ll);
 }
 
+/* Can this context's chains run one per wavefront (mcmc_wave_kernel.hip.h)?  `why` names the obstacle. */
+bool wave_mapping_possible(const mcmc_hip_ctx* c, const char** why) {
+    const char* w = nullptr;
+    if (c->multi) w = "the multi-region model runs one chain per lane only";
+    else if (c->precision != MCMC_HIP_PRECISION_F64) w = "the fast mode runs one chain per lane only";
+    else if (!c->cfg.contract) w = "one chain per wavefront needs cfg.contract = 1 (its matrix instruction is a fused multiply-add)";
+    else if (wave_lds_bytes(c->M, c->dim) > kLdsMax) w = "the series is too long for a chain's slice of LDS";
+    if (why) *why = w;
+    return w == nullptr;
+}
+void decide_mapping(mcmc_hip_ctx* c) {
+    const bool ok = wave_mapping_possible(c, nullptr);
+    c->useWave = ok && (c->mapping == MCMC_HIP_MAPPING_WAVE ||
+                        (c->mapping == MCMC_HIP_MAPPING_AUTO && c->nChains > 0 && c->nChains <= MCMC_WAVE_AUTO_MAX));
+}
+
+int launch_wave_steps(mcmc_hip_ctx* c, int nSteps, const double* dBetas, const int* dFlags, int slot0) {
+    const unsigned grid = (unsigned)((c->nChains + MCMC_WAVES_PER_BLOCK - 1) / MCMC_WAVES_PER_BLOCK);
+    size_t shmem = wave_lds_bytes(c->M, c->dim);
+    if (shmem > kLdsMax) return fail(MCMC_HIP_EINVAL, "the series is too long for a chain's slice of LDS (%zu B > %zu B)", shmem, kLdsMax);
+    if (grid <= (unsigned)c->nCU && shmem < kLdsSolo) shmem = kLdsSolo;      /* one workgroup per CU while CUs are idle */
+    HIP_TRY(hipFuncSetAttribute((const void*)mh_step_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(mh_step_wave_kernel, dim3(grid), dim3(MCMC_BLOCK), shmem, c->stream, c->M, c->S, nSteps, dBetas, dFlags, slot0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_steps(mcmc_hip_ctx* c, int nSteps, const double* dBetas, const int* dFlags, int slot0) {
     const long long hc = c->headCounter;
+    if (c->useWave) return launch_wave_steps(c, nSteps, dBetas, dFlags, slot0);
     if (c->multi) {
         if (c->cfg.contract)
             return launch_chain_kernel(c, mh_step_kernel<MCMC_T, true, 0, true>, false, MCMC_T, c->M, c->S, nSteps, dBetas, dFlags, slot0, hc);
@@ -674,6 +708,7 @@ int mcmc_hip_set_precision(mcmc_hip_ctx* c, int32_t mode) try {
     }
     c->precision = mode;
     c->haveChains = false;             /* log-likelihoods of the other arithmetic are not comparable */
+    decide_mapping(c);
     return 0;
 } MCMC_ABI_GUARD
 
@@ -754,8 +789,27 @@ int mcmc_hip_set_chains(mcmc_hip_ctx* c, int64_t n_chains, const double* params,
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->haveChains = true;
     c->stepsDone = 0;
+    decide_mapping(c);
     return 0;
 } MCMC_ABI_GUARD
+
+int mcmc_hip_set_mapping(mcmc_hip_ctx* c, int32_t mapping) try {
+    if (int r = check_ctx(c)) return r;
+    if (mapping != MCMC_HIP_MAPPING_AUTO && mapping != MCMC_HIP_MAPPING_LANE && mapping != MCMC_HIP_MAPPING_WAVE)
+        return fail(MCMC_HIP_EINVAL, "set_mapping: unknown mapping %d", mapping);
+    if (mapping == MCMC_HIP_MAPPING_WAVE) {
+        const char* why = nullptr;
+        if (!wave_mapping_possible(c, &why)) return fail(MCMC_HIP_EINVAL, "set_mapping: %s", why);
+    }
+    c->mapping = mapping;
+    decide_mapping(c);
+    return 0;
+} MCMC_ABI_GUARD
+
+int32_t mcmc_hip_get_mapping(const mcmc_hip_ctx* c) {
+    if (!c) return MCMC_HIP_EINVAL;
+    return c->useWave ? MCMC_HIP_MAPPING_WAVE : MCMC_HIP_MAPPING_LANE;
+}
 
 int mcmc_hip_set_state(mcmc_hip_ctx* c, const uint64_t* rng_state, const double* loglike, const double* mean,
                        const int32_t* accept_counts) try {

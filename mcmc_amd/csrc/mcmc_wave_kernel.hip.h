@@ -1,0 +1,431 @@
+/*
+ * mcmc_wave_kernel.hip.h -- the SMALL-ENSEMBLE mapping of the Metropolis-Hastings step: one chain per
+ * WAVEFRONT instead of one chain per lane (EXTENSION beside north_star's mapping; same arithmetic, same bits).
+ *
+ * Why: with one chain per lane BASELINE configs[1] (1 024 chains x 200 days) is 16 wavefronts on a chip of
+ * 1 024 SIMDs.  The model's only parallelism inside one chain is (destination day) x (compartment): every
+ * accumulator buf_c[j] receives its addends n_k * R_c[j-k] in ascending source day k (that order is the
+ * reference's, covid.h:376-386, and fixes the bits), but the 7 compartments and the days of a block are
+ * independent of each other.  This kernel gives a chain a whole wavefront and spreads a block of 16 days x 7
+ * compartments over it:
+ *
+ *   phase A  (sources before the block)   C[c][t] = sum over lags L of R_c[L] * n_{j0+t-L}  is a matrix product
+ *            with A[m = c][k = L] = table, B[k = L][n = t] = history (Toeplitz), and v_mfma_f64_16x16x4_f64 is,
+ *            bit for bit, the chain fma(a3,b3,fma(a2,b2,fma(a1,b1,fma(a0,b0,C)))) (tools/ubench/mfma_f64.hip:
+ *            0 mismatches) -- with the K slots holding DESCENDING lags that is ascending source days, the order
+ *            the parity bar needs.  One MFMA = 4 lags x 16 days x 7 compartments; both operands come from LDS
+ *            (the workgroup's table image, the wave's own history).  Lags whose source day carries a hospital-
+ *            capacity correction (covid.h:413-429) go one lag per MFMA, the K slots holding that source day's
+ *            three operations in the reference's order: n_k * R_c[L], then + e_k (deaths), then - e_k * FromSerious[L].
+ *   phase B  (the block's 16 days in order; the feedback n_{i+1} = f(buffers[i]) is sequential, covid.h:461-462)
+ *            today's n_i goes into today's and the later days' accumulators from registers (one multiply-add per
+ *            lane), the seven sums of today are fetched with v_readlane and the day's scalar arithmetic runs
+ *            uniformly in every lane.
+ *
+ * Everything a chain touches during a launch -- parameter vector, proposal, both histories, weighted deaths --
+ * lives in the wave's slice of LDS; HBM is read at the start of a launch and written at its end (and by
+ * recording).  The proposal's behaviour nodes, the prior's and the likelihood's terms are computed one per
+ * lane and summed in the reference's order.  Only FP64 with FMA contraction (cfg.contract = 1: an MFMA is
+ * fused), only the single-region State.  The host picks the mapping by ensemble size (mcmc_hip_set_mapping);
+ * tests/test_gpu_wave_mapping.py holds it bit-exact to the oracle AND to the chain-per-lane kernel.
+ */
+#pragma once
+
+#define MCMC_WV_T 16          /* days per block = the 16 columns of the MFMA tile */
+#define MCMC_WV_HLO 24        /* zero history entries kept below day 0 (phase A reads down to s - 15) */
+#define MCMC_WV_HHI 24        /* ... and above the simulated horizon (phase A reads up to j0 + 17, as zeros) */
+
+__host__ __device__ inline size_t wave_slice_doubles(const DevModel& M, int dim) {
+    const size_t histLen = (size_t)M.simDays + MCMC_WV_HLO + MCMC_WV_HHI;
+    const size_t terms = (size_t)(M.nData > M.nB ? M.nData : M.nB);
+    return 2 * histLen + 2 * (size_t)M.nData + terms + 2 * (size_t)dim;
+}
+__host__ __device__ inline size_t wave_lds_bytes(const DevModel& M, int dim) {
+    return ((lds_bytes(M, false, MCMC_WV_T) + 7) / 8 + (size_t)MCMC_WAVES_PER_BLOCK * wave_slice_doubles(M, dim)) * sizeof(double);
+}
+
+/* the wave's slice */
+struct WaveSlice {
+    double* hn;        /* [histLen] infections per day, day k at hn[k + MCMC_WV_HLO] */
+    double* he;        /* [histLen] extra deaths per day                            */
+    double* d1;        /* [nData] weighted deaths of the first pass (shift 1)       */
+    double* d0;        /* [nData] ... of the second                                 */
+    double* terms;     /* [max(nData, nB)] per-day / per-node terms awaiting their ordered sum */
+    double* xc;        /* [dim] current parameter vector                            */
+    double* xp;        /* [dim] proposal                                            */
+    int histLen;
+};
+
+__device__ __forceinline__ void wave_sync() {
+    /* LDS operations of one wave execute in order; this only keeps the compiler from moving accesses across */
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int srcLane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double uniform_f64(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+/*
+ * DiseaseSpread::eval (covid.h:325-496) of the parameter vector W.xp for the chain of this WAVE.  Every lane
+ * returns the same loglike.  Same operations on every accumulator, in the same order, as eval_model<T, true>.
+ */
+__device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsView& lds, const WaveSlice& W,
+                                                  const LaneScalars& lp, unsigned lane, WorkCount& work, int ldsRows) {
+    const int md = M.md;
+    const int horizon = M.simDays;
+    const int q = (int)(lane >> 4), n = (int)(lane & 15);     /* MFMA result: rows q, q+4 (, q+8, q+12) of column n */
+    const int kk = q, m = n;                                   /* MFMA operands: A[m][kk], B[kk][n]                  */
+    const int rowsM1 = ldsRows - 1;
+    const double* xdisc = W.xp + M.nB;
+
+    double loglike = 0;                                             /* covid.h:329 */
+    int start = (int)((double)md - lp.delay);                       /* covid.h:331 */
+    const double frac = (double)md - lp.delay - (double)start;      /* covid.h:332 */
+    start = min(max(start, 0), horizon);
+    start = __builtin_amdgcn_readfirstlane(start);
+    count_work(M, start, work);
+
+#pragma unroll 1
+    for (int shift = 1; shift >= 0; --shift) {                      /* covid.h:335 */
+        const double w = (double)(1 - shift) * (1.0 - frac) + (double)shift * frac; /* covid.h:333 */
+        const int s = min(start + shift, horizon);
+        int keLo = 0x7fffffff, keHi = -1;                           /* source days with a capacity correction */
+        for (int k = (int)lane; k < W.histLen; k += MCMC_WAVE) { W.hn[k] = 0.0; W.he[k] = 0.0; }
+        wave_sync();
+        double ncur = 1.0;                                          /* patient zero on day s, covid.h:339 */
+        double* ds = shift == 1 ? W.d1 : W.d0;
+
+#pragma unroll 1
+        for (int j0 = s; j0 < horizon; j0 += MCMC_WV_T) {
+            double4_t c = {0.0, 0.0, 0.0, 0.0};
+            /* ---------- phase A: sources k < j0 (entries >= j0 of the history are still zero) */
+            if (j0 > s) {
+                const bool anyE = keHi >= keLo;
+                const int eLagLo = j0 - keHi, eLagHi = j0 + (MCMC_WV_T - 1) - keLo;
+                const int Lhi = j0 + (MCMC_WV_T - 1) - s;
+                const double* hnB = W.hn + MCMC_WV_HLO + j0 + n;       /* source day of lag L: j0 + n - L */
+                const double* heB = W.he + MCMC_WV_HLO + j0 + n;
+#pragma unroll 1
+                for (int L0 = Lhi; L0 >= 1; L0 -= 4) {
+                    if (!(anyE && L0 >= eLagLo && L0 - 3 <= eLagHi)) {
+                        const int L = L0 - kk;
+                        const double a = lds.Rpos[min(max(L, 0), rowsM1) * 8 + (m & 7)];
+                        const double b = hnB[-L];
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+                    } else {
+#pragma unroll 1
+                        for (int L = L0; L > L0 - 4 && L >= 1; --L) {
+                            const int Lr = min(L, rowsM1);
+                            /* K slots: n_k R_c[L]; + e_k (deaths: the flat add() of covid.h:387-391, cut after
+                             * traj.nDays lags like project()); - e_k x the three FromSerious curves; nothing */
+                            double a = 0.0, b = 0.0;
+                            if (kk == 0) { a = lds.Rpos[Lr * 8 + (m & 7)]; b = hnB[-L]; }
+                            else if (kk == 1) { a = (m == A_DEAD) ? lds.Rneg[Lr * 4 + 3] : 0.0; b = heB[-L]; }
+                            else if (kk == 2) { a = (m >= A_SER && m <= A_DEAD) ? lds.Rneg[Lr * 4 + (m - A_SER)] : 0.0; b = -heB[-L]; }
+                            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            /* ---------- phase B: the block's days in order.  c[0] = (MI, HI, INC, MILD)[q] of day n, c[1] = (SER, REC, DEAD, -)[q] */
+#pragma unroll
+            for (int t = 0; t < MCMC_WV_T; ++t) {
+                const int i = j0 + t;
+                if (i >= horizon) break;
+                W.hn[MCMC_WV_HLO + i] = ncur;
+                /* today's new infections into today and the rest of the block (covid.h:403-410) */
+                if (n >= t) {
+                    const int d = n - t;
+                    c[0] = __builtin_fma(ncur, lds.Rpos[d * 8 + q], c[0]);
+                    c[1] = __builtin_fma(ncur, lds.Rpos[d * 8 + 4 + q], c[1]);     /* q = 3: the table's zero column */
+                }
+                const double vMI = readlane_f64(c[0], t), vHI = readlane_f64(c[0], 16 + t), vINC = readlane_f64(c[0], 32 + t),
+                             vMILD = readlane_f64(c[0], 48 + t);
+                double vSER = readlane_f64(c[1], t), vREC = readlane_f64(c[1], 16 + t), vDEAD = readlane_f64(c[1], 32 + t);
+                /* hospital capacity (covid.h:413-429) */
+                const double overCapacity = vSER * M.probICU - lds.capacity[i];
+                const double extraDeaths = M.probLethal * overCapacity;
+                if (__builtin_amdgcn_readfirstlane((extraDeaths > 0) ? 1 : 0)) {
+                    const double e = extraDeaths, ne = -extraDeaths;
+                    W.he[MCMC_WV_HLO + i] = e;
+                    keLo = min(keLo, i);
+                    keHi = max(keHi, i);
+                    if (n >= t && q < 3) {
+                        const int d = n - t;
+                        if (q == 2) c[1] = c[1] + e;
+                        c[1] = __builtin_fma(ne, lds.Rneg[d * 4 + q], c[1]);
+                    }
+                    vDEAD = vDEAD + e;                                              /* today's own sums, the same operations */
+                    vSER = __builtin_fma(ne, lds.Rneg[0], vSER);
+                    vREC = __builtin_fma(ne, lds.Rneg[1], vREC);
+                    vDEAD = __builtin_fma(ne, lds.Rneg[2], vDEAD);
+                }
+                /* piecewise-constant factor and behaviour (covid.h:432-454) */
+                const int sg = lds.seg[i];
+                const double pcf = sg >= 0 ? xdisc[max(sg, 0)] : 1.0;
+                double smoothbehavior = 1.0;
+                if (i >= md) smoothbehavior = pcf * W.xp[min(max(i - md, 0), M.nB - 1)];
+                const double totalBehavior = pcf * smoothbehavior;
+                /* tomorrow's new infections (covid.h:461-462); asymptomatic == mild buffer */
+                const double nSus = M.pop - vINC - vMILD - vMILD - vSER - vREC - vDEAD;
+                const double nnext = totalBehavior * nSus / M.pop * (lp.betaMild * vMI + lp.betaHigh * vHI);
+                if (i >= md && i - md < M.nData) ds[i - md] = w * vDEAD;            /* covid.h:475,484 */
+                ncur = nnext;
+            }
+            wave_sync();
+        }
+        /* log-likelihood of this pass (covid.h:488-492): one term per lane, then the sum in day order */
+        wave_sync();
+        for (int i = (int)lane; i < M.nData; i += MCMC_WAVE) {
+            double dv = W.d1[i];
+            if (shift == 0) dv = dv + W.d0[i];
+            const double delta = dv - lds.deaths[i];
+            W.terms[i] = w * (-0.5 * delta * delta / lds.sigma2[i]);
+        }
+        wave_sync();
+#pragma unroll 8
+        for (int i = 0; i < M.nData; ++i) loglike += W.terms[i];
+        wave_sync();
+    }
+    return loglike;
+}
+
+/*
+ * DiseaseSpread::step up to the eval call (covid.h:499-622) for the chain of this wave: the draws and the scalar
+ * moves run uniformly in every lane, the behaviour nodes one per lane.  Mirrors propose() line by line.
+ */
+__device__ inline bool propose_wave(const DevModel& M, Pcg32& rnd, const WaveSlice& W, unsigned lane, double stepsize,
+                                    LaneScalars& lp, double& priorOut) {
+    const double* xc = W.xc;
+    double* xp = W.xp;
+    lp.betaMild = xc[M.nB + M.nDisc];
+    lp.betaHigh = xc[M.nB + M.nDisc + 1];
+    lp.delay = xc[M.nB + M.nDisc + 2];
+    double disc[MCMC_MAXDISC];
+#pragma unroll
+    for (int k = 0; k < MCMC_MAXDISC; ++k) disc[k] = (k < M.nDisc) ? xc[M.nB + k] : 1.0;
+    const double sfmin = fmin(stepsize, 1.0);
+
+    const bool big1 = rnd.next_float() < 0.6f;                      /* covid.h:503-507 */
+    const bool big2 = rnd.next_float() < 0.6f;
+    const bool big3 = rnd.next_float() < 0.6f;
+    const bool big4 = rnd.next_float() < 0.6f;
+    const bool big5 = rnd.next_float() < 0.6f;
+
+    if (rnd.next_float() < 0.3f) {                                  /* covid.h:510-515 */
+        lp.delay += (rnd.next_double() - 0.5) * 0.5 * 0.1 * sfmin;
+        if (big1) lp.delay += (rnd.next_double() - 0.5) * sfmin;
+        lp.delay = bound_reflect(lp.delay, 5.0, (double)M.md);
+    }
+    if (rnd.next_float() < 0.3f) {                                  /* covid.h:518-532 */
+        if (!big2) lp.betaMild += (rnd.next_double() - 0.5) * 0.1 * sfmin;
+        else lp.betaMild += (rnd.next_double() - 0.5) * sfmin;
+        lp.betaMild = bound_reflect(lp.betaMild, 0.0, 100.0);
+        if (!big3) lp.betaHigh += (rnd.next_double() - 0.5) * 0.1 * sfmin;
+        else lp.betaHigh += (rnd.next_double() - 0.5) * sfmin;
+        lp.betaHigh = bound_reflect(lp.betaHigh, 0.0, 100.0);
+        if (lp.betaHigh < lp.betaMild) {
+            const double t = lp.betaHigh; lp.betaHigh = lp.betaMild; lp.betaMild = t;
+        }
+    }
+    if (rnd.next_float() < 0.9f) {                                  /* covid.h:557-598 */
+        const bool reverse = rnd.next_double() < 0.5;
+        const int nD = M.nDisc;
+#define MCMC_VISIT(i)                                                                        \
+        if ((i) < nD && !((M.discFixedMask >> (i)) & 1u)) {                                  \
+            const float xx = rnd.next_float();                                               \
+            if (xx < M.discThr) {                                                            \
+                if (!big4) disc[i] += (rnd.next_double() - 0.5) * 0.1 * sfmin;               \
+                else disc[i] += (rnd.next_double() - 0.5) * sfmin;                           \
+                double lower = 0, upper = 1;                                                 \
+                if ((i) >= 1) upper = disc[(i) >= 1 ? (i) - 1 : 0];                          \
+                if ((i) < nD - 1) lower = disc[(i) + 1 < MCMC_MAXDISC ? (i) + 1 : 0];        \
+                disc[i] = bound_reflect(disc[i], lower, upper);                              \
+            }                                                                                \
+        }
+        if (!reverse) {
+            MCMC_VISIT(0) MCMC_VISIT(1) MCMC_VISIT(2) MCMC_VISIT(3)
+            MCMC_VISIT(4) MCMC_VISIT(5) MCMC_VISIT(6) MCMC_VISIT(7)
+        } else {
+            MCMC_VISIT(7) MCMC_VISIT(6) MCMC_VISIT(5) MCMC_VISIT(4)
+            MCMC_VISIT(3) MCMC_VISIT(2) MCMC_VISIT(1) MCMC_VISIT(0)
+        }
+#undef MCMC_VISIT
+    }
+    bool doB = false;
+    double omega = 0, A = 0;
+    if (rnd.next_float() < 0.3f) {                                  /* covid.h:601-622 */
+        doB = true;
+        const double xx = rnd.next_double();
+        omega = 2 * 3.1415 / M.dNData * 5 * xx * xx;
+        A = sfmin * 0.1 * (rnd.next_double() - 0.5);
+        if (big5) A += sfmin * (rnd.next_double() - 0.5);
+    }
+    doB = __builtin_amdgcn_readfirstlane(doB ? 1 : 0) != 0;
+    priorOut = 0.0;
+    const int nB = M.nB;
+    if (doB) {
+        for (int i = (int)lane; i < nB; i += MCMC_WAVE)
+            xp[i] = bound_reflect(xc[i] + A * (mcmc_cos(omega * (double)i) - 1), 0.0, 2.0);
+        wave_sync();
+        /* SmoothnessPrior::eval of the proposal (mcmc.h:197-214): the terms one per lane, their sum in node order */
+        const double dx = M.smoothL / (double)nB;
+        const bool dxPow2 = is_pow2(dx);
+        const double invDx = 1.0 / dx;
+        for (int i = 2 + (int)lane; i < nB; i += MCMC_WAVE) {
+            const double v = xp[i], f0 = xp[i - 1], fm = xp[i - 2];
+            const double dd = v + fm - 2 * f0;
+            W.terms[i] = div3(dd * dd, dx, dxPow2, invDx);
+        }
+        wave_sync();
+        double loglike = 0;
+#pragma unroll 8
+        for (int i = 2; i < nB; ++i) loglike -= W.terms[i];
+        loglike *= M.smoothLs * M.smoothLs / M.smoothL;
+        priorOut = loglike;
+        wave_sync();
+    } else {
+        for (int i = (int)lane; i < nB; i += MCMC_WAVE) xp[i] = xc[i];
+    }
+    if (lane < (unsigned)M.nDisc) {
+        double v = disc[0];
+#pragma unroll
+        for (int k = 1; k < MCMC_MAXDISC; ++k) v = (lane == (unsigned)k) ? disc[k] : v;
+        xp[nB + lane] = v;
+    }
+    if (lane == 0) {
+        xp[nB + M.nDisc] = lp.betaMild;
+        xp[nB + M.nDisc + 1] = lp.betaHigh;
+        xp[nB + M.nDisc + 2] = lp.delay;
+    }
+    wave_sync();
+    return doB;
+}
+
+/*
+ * n_steps Metropolis-Hastings steps for every chain, one chain per wavefront: the same schedule, draws,
+ * arithmetic and results as mh_step_kernel<T, true, 0, false> (see there for the reference citations).
+ * Grid: ceil(nChains / 4) workgroups of 4 waves sharing one LDS image of the tables and the series.
+ */
+__global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, int n_steps,
+                                                      const double* __restrict__ betas,
+                                                      const int* __restrict__ flags, int slot0) {
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    const LdsView lds = stage_lds(M, lds_raw, false, MCMC_WV_T);
+    const int ldsRows = lds_rows(M, false, MCMC_WV_T);
+    const unsigned lane = threadIdx.x & (MCMC_WAVE - 1);
+    const int waveInBlock = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / MCMC_WAVE));
+    const long long chain = (long long)blockIdx.x * MCMC_WAVES_PER_BLOCK + waveInBlock;
+    if (chain >= S.nChains) return;
+    const int tile = (int)(chain / MCMC_WAVE);
+    const int lit = (int)(chain % MCMC_WAVE);                       /* the chain's lane in the tile-major arrays */
+    const int dim = S.dim;
+
+    WaveSlice W;
+    W.histLen = M.simDays + MCMC_WV_HLO + MCMC_WV_HHI;
+    {
+        double* p = lds_raw + (lds_bytes(M, false, MCMC_WV_T) + 7) / 8 + (size_t)waveInBlock * wave_slice_doubles(M, dim);
+        W.hn = p; p += W.histLen;
+        W.he = p; p += W.histLen;
+        W.d1 = p; p += M.nData;
+        W.d0 = p; p += M.nData;
+        W.terms = p; p += (M.nData > M.nB ? M.nData : M.nB);
+        W.xc = p; p += dim;
+        W.xp = p;
+    }
+    double* xg = S.params + (size_t)tile * dim * MCMC_WAVE + lit;   /* element k at xg[k * 64] */
+    for (int k = (int)lane; k < dim; k += MCMC_WAVE) W.xc[k] = xg[(size_t)k * MCMC_WAVE];
+    for (int k = (int)lane; k < M.nData; k += MCMC_WAVE) { W.d1[k] = 0.0; W.d0[k] = 0.0; }
+    uint64_t* rng_g = S.rng + (size_t)tile * 2 * MCMC_WAVE + lit;
+    double* ll_g = S.ll + (size_t)tile * 2 * MCMC_WAVE + lit;
+    double* ss_g = S.stepsize + (size_t)tile * MCMC_WAVE + lit;
+    const size_t flat = (size_t)tile * MCMC_WAVE + lit;
+    unsigned long long* pairs_g = S.pairs + (size_t)tile * 2 * MCMC_WAVE + lit;
+
+    Pcg32 rnd;
+    rnd.state = rng_g[0];
+    rnd.inc = rng_g[MCMC_WAVE];
+    double llModel = ll_g[0], llPrior = ll_g[MCMC_WAVE], stepsize = ss_g[0];
+    int nAccept = S.nAccept[flat];
+    WorkCount work;
+    work.algo = pairs_g[0];
+    work.exec = pairs_g[MCMC_WAVE];
+    const double rungBeta = S.chainBeta ? S.chainBeta[flat] : 1.0;
+    int slot = slot0;
+    wave_sync();
+
+#pragma unroll 1
+    for (int g = 0; g < n_steps; ++g) {
+        const int fl = flags[g];
+        const double beta = betas[g] * rungBeta;
+        if (fl & SF_RESET_ACC) nAccept = 0;                         /* mcmc.h:1032,1090 */
+        if (fl & SF_RECORD) {                                       /* mcmc.h:1037-1062 */
+            double l = 0;
+            l += llModel;
+            if (M.hasPrior) l += llPrior;
+            if (lane == 0) S.recLL[((size_t)slot * S.nTiles + tile) * MCMC_WAVE + lit] = 0.0 + beta * l;
+            if (S.recSamples) {
+                double* dst = S.recSamples + ((size_t)slot * S.nTiles + tile) * (size_t)dim * MCMC_WAVE + lit;
+                for (int k = (int)lane; k < dim; k += MCMC_WAVE) dst[(size_t)k * MCMC_WAVE] = W.xc[k];
+            }
+            ++slot;
+        }
+        if ((fl & SF_MEAN) && S.mean) {                             /* mcmc.h:1064-1065 */
+            double* mu = S.mean + (size_t)tile * dim * MCMC_WAVE + lit;
+            for (int k = (int)lane; k < dim; k += MCMC_WAVE) mu[(size_t)k * MCMC_WAVE] += W.xc[k];
+        }
+        if (fl & SF_RANDOM) {                                       /* mcmc.h:494-500 */
+            const int nState = M.hasPrior ? 2 : 1;
+            int hd;
+            do {
+                const float f = rnd.next_float() * (float)nState;
+                hd = min((int)f, nState - 1);
+            } while (hd != 0);
+        }
+        LaneScalars lp;
+        double llpNew;
+        const bool behChanged = propose_wave(M, rnd, W, lane, stepsize, lp, llpNew);
+        const double llm = eval_model_wave(M, lds, W, lp, lane, work, ldsRows);
+        double llp = 0.0;
+        double delta = 0;                                           /* mcmc.h:604-606 */
+        delta += -llModel + llm;
+        if (M.hasPrior) {
+            llp = behChanged ? llpNew : llPrior;
+            delta += -llPrior + llp;
+        }
+        delta += 0.0;                                               /* mcmc.h:765 */
+        delta *= beta;                                              /* mcmc.h:766 */
+        const double u = (double)rnd.next_float();
+        const bool accept = __builtin_amdgcn_readfirstlane((u < 1.0 * mcmc_exp(delta)) ? 1 : 0) != 0;   /* mcmc.h:776 */
+        if (accept) {                                               /* State::accept, mcmc.h:653-661 */
+            for (int k = (int)lane; k < dim; k += MCMC_WAVE) W.xc[k] = W.xp[k];
+            llModel = llm;
+            llPrior = llp;
+            ++nAccept;
+        }
+        wave_sync();
+        if (fl & SF_ADJUST_END) {                                   /* mcmc.h:1107-1114 */
+            const double acceptRate = (double)nAccept / 20;
+            stepsize *= rate2corr(acceptRate);
+        }
+    }
+
+    for (int k = (int)lane; k < dim; k += MCMC_WAVE) xg[(size_t)k * MCMC_WAVE] = W.xc[k];
+    if (lane == 0) {
+        rng_g[0] = rnd.state;
+        ll_g[0] = llModel;
+        ll_g[MCMC_WAVE] = llPrior;
+        ss_g[0] = stepsize;
+        S.nAccept[flat] = nAccept;
+        pairs_g[0] = work.algo;
+        pairs_g[MCMC_WAVE] = work.exec;
+    }
+}

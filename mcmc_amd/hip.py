@@ -22,7 +22,7 @@ OUT_CURVES = ["mildlyInfectious", "highlyInfectious", "incubating", "asymptomati
 SYMBOLS = [
     "mcmc_hip_last_error", "mcmc_hip_device_count", "mcmc_host_make_response_tables",
     "mcmc_host_default_disease_params", "mcmc_host_perturb_ics", "mcmc_host_perturb_ics_from", "mcmc_hip_create",
-    "mcmc_hip_destroy", "mcmc_hip_set_tables", "mcmc_hip_set_data", "mcmc_hip_set_precision", "mcmc_hip_set_chains",
+    "mcmc_hip_destroy", "mcmc_hip_set_tables", "mcmc_hip_set_data", "mcmc_hip_set_precision", "mcmc_hip_set_mapping", "mcmc_hip_get_mapping", "mcmc_hip_set_chains",
     "mcmc_hip_set_state", "mcmc_hip_set_regions", "mcmc_hip_n_regions", "mcmc_hip_get_region_loglike",
     "mcmc_hip_get_region_stepsizes", "mcmc_hip_get_scan_position", "mcmc_hip_set_region_state",
     "mcmc_hip_run", "mcmc_hip_step", "mcmc_hip_n_saved", "mcmc_hip_dim", "mcmc_hip_size",
@@ -83,6 +83,8 @@ def lib():
     L.mcmc_hip_set_tables.argtypes = [vp, dp, C.c_int32]
     L.mcmc_hip_set_data.argtypes = [vp, dp, dp]
     L.mcmc_hip_set_precision.argtypes = [vp, C.c_int32]
+    L.mcmc_hip_set_mapping.argtypes = [vp, C.c_int32]
+    L.mcmc_hip_get_mapping.argtypes = [vp]
     L.mcmc_hip_set_chains.argtypes = [vp, C.c_int64, dp, dp, C.POINTER(C.c_uint64), C.c_uint64]
     L.mcmc_hip_set_regions.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), dp, dp, dp, dp]
     L.mcmc_hip_n_regions.argtypes = [vp]
@@ -259,6 +261,16 @@ class CovidSampler:
         convolution in packed FP32; statistical bar, see include/mcmc_hip.h).  Before set_chains."""
         _check(lib().mcmc_hip_set_precision(self._h, self.PRECISIONS[precision]))
         self.n_chains = 0
+
+    MAPPINGS = {"auto": 0, "lane": 1, "wave": 2}                        # MCMC_HIP_MAPPING_*
+
+    def set_mapping(self, mapping):
+        """"lane" (one chain per lane), "wave" (one chain per wavefront: small ensembles) or "auto"; results do
+        not depend on it (include/mcmc_hip.h at mcmc_hip_set_mapping)."""
+        _check(lib().mcmc_hip_set_mapping(self._h, self.MAPPINGS[mapping]))
+
+    def mapping(self):
+        return {1: "lane", 2: "wave"}[lib().mcmc_hip_get_mapping(self._h)]
 
     def set_regions(self, cfgs):
         """multi-region model (extension, BASELINE configs[4]): cfgs = per-region config dicts that differ in
