@@ -300,6 +300,9 @@ def main():
     ap.add_argument("--start-spread", type=float, default=None,
                     help="relative spread of the chains' starting points around the generating parameters "
                          "(State::perturb's rule, mcmc.h:306-314); default 0.01 as SURVEY 8d, 0.001 with --regions")
+    ap.add_argument("--mapping", default="auto", choices=["auto", "lane", "wave"],
+                    help="chains onto the GPU: one per lane, one per wavefront (small ensembles), or the library's choice "
+                         "(wave up to 16384 chains); no effect on results (include/mcmc_hip.h, mcmc_hip_set_mapping)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-leg", action="store_true", help="skip the FP32 fast-mode leg (N=1 only)")
     ap.add_argument("--no-strict-leg", action="store_true", help="skip the strict (no FMA contraction) leg (N=1 only)")
@@ -384,6 +387,8 @@ def main():
         cfg["dim"] = s.dim
     else:
         cfg, R, xs, s = build_workload(device, n_chains, first_id, args.contract, n_data=n_data, precision=args.precision, spread=args.start_spread)
+        if args.mapping != "auto":
+            s.set_mapping(args.mapping)
     fast_main = args.precision != "f64"
     peak = PEAK_FP32_VECTOR_TFLOPS if fast_main else PEAK_FP64_VECTOR_TFLOPS
 
@@ -438,7 +443,7 @@ def main():
         total_steps = n_total * args.steps
         value = total_steps / dt
         n_simd = 4 * torch.cuda.get_device_properties(device).multi_processor_count
-        n_waves = (n_chains + 63) // 64
+        n_waves = n_chains if s.mapping() == "wave" else (n_chains + 63) // 64
         # roofline of the dominant kernel (mh_step_kernel) on this rank
         ksec = t_after["step_kernel_s"] - t_before["step_kernel_s"]
         launches = t_after["launches"] - t_before["launches"]
@@ -452,7 +457,7 @@ def main():
         # committed profile of the same kernel and scaled per chain-step, with its source named
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_fast_mode.json" if fast_main else "traffic_latest.json")
-        if os.path.exists(tpath) and n_data == N_DATA and not args.regions:     # bytes per chain-step depend on the series length
+        if os.path.exists(tpath) and n_data == N_DATA and not args.regions and s.mapping() == "lane":     # bytes per chain-step depend on the series length
             try:
                 tj = json.load(open(tpath))
                 per_chain_step = tj["hbm_bytes_per_launch"] / (tj.get("chains", CHAINS_PER_GPU) * tj.get("steps_per_launch", STEPS_PER_LAUNCH))
@@ -477,6 +482,7 @@ def main():
                                     ("1" if (n_chains, n_data) == (1024, 200) else "3" if args.ladder else
                                      "2" if n_data == N_DATA else "2 shape, other length")),
                        **({"regions": args.regions, "dim_per_region": cfgs[0]["dim"]} if args.regions else {}),
+                       "mapping": s.mapping() + (" (one chain per wavefront, mcmc_wave_kernel.hip.h)" if s.mapping() == "wave" else " (one chain per lane)"),
                        "chains_per_gpu": n_chains, "chains_total": n_total, "n_data": n_data, "dim": cfg["dim"],
                        # one chain per lane: how much of the chip this ensemble can occupy at all
                        "occupancy": {"waves_per_gpu": n_waves, "simds_per_gpu": n_simd, "frac": min(1.0, n_waves / n_simd)},
@@ -491,7 +497,8 @@ def main():
                        "parallelism": f"chain-shard x{world}"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "mh_step_kernel",
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "mh_step_wave_kernel" if s.mapping() == "wave" else "mh_step_kernel",
                          "kernel_ms_per_launch": 1e3 * ksec / max(launches, 1), "launches": launches,
                          "steps_per_launch": args.steps / max(launches, 1),
                          "algorithmic_flops_per_launch": flops / max(launches, 1),

@@ -31,9 +31,10 @@
  */
 #pragma once
 
-#define MCMC_WV_T 16          /* days per block = the 16 columns of the MFMA tile */
+#define MCMC_WV_T 16          /* the 16 columns of the MFMA tile: days per HALF block */
+#define MCMC_WV_B 32          /* days per block: rows 0..6 of the tile hold the block's days 0..15, rows 8..14 its days 16..31 */
 #define MCMC_WV_HLO 24        /* zero history entries kept below day 0 (phase A reads down to s - 15) */
-#define MCMC_WV_HHI 24        /* ... and above the simulated horizon (phase A reads up to j0 + 17, as zeros) */
+#define MCMC_WV_HHI 40        /* ... and above the simulated horizon (phase A reads up to j0 + 18, as zeros; j0 <= horizon - 1) */
 
 __host__ __device__ inline size_t wave_slice_doubles(const DevModel& M, int dim) {
     const size_t histLen = (size_t)M.simDays + MCMC_WV_HLO + MCMC_WV_HHI;
@@ -73,12 +74,44 @@ __device__ __forceinline__ double uniform_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 
+/* What phase B multiplies with never changes: the lane that holds (compartment row q / 4 + q, day n) of a block
+ * needs, on the block's day t, the table rows of lag n - t -- or nothing if its day is already over.  Loaded once
+ * per launch; a zero stands for "day over" (the multiply-add then leaves the finished sum, which nobody reads
+ * again, unchanged). */
+struct WaveRows {
+    double p0[MCMC_WV_T];     /* R_q[n - t]      (MI, HI, INC, MILD) */
+    double p1[MCMC_WV_T];     /* R_{4+q}[n - t]  (SER, REC, DEAD, 0) */
+    double ng[MCMC_WV_T];     /* the FromSerious curve of SER / REC / DEAD at lag n - t, else 0 */
+    double f0[MCMC_WV_T];     /* the same three at lag 16 + n - t: what a day t < 16 pushes into the block's second half */
+    double f1[MCMC_WV_T];
+    double fg[MCMC_WV_T];
+    double ng0[3];            /* the three FromSerious curves at lag 0 (today's own sums), the same in every lane */
+};
+__device__ __forceinline__ void load_wave_rows(const LdsView& lds, unsigned lane, WaveRows& R) {
+    const int q = (int)(lane >> 4), n = (int)(lane & 15);
+#pragma unroll
+    for (int t = 0; t < MCMC_WV_T; ++t) {
+        const int d = n - t;
+        const int dd = max(d, 0);
+        const double a = lds.Rpos[dd * 8 + q], b = lds.Rpos[dd * 8 + 4 + q], g = lds.Rneg[dd * 4 + min(q, 2)];
+        R.p0[t] = d >= 0 ? a : 0.0;
+        R.p1[t] = d >= 0 ? b : 0.0;
+        R.ng[t] = (d >= 0 && q < 3) ? g : 0.0;
+        const int df = MCMC_WV_T + n - t;                               /* 1 .. 31 */
+        R.f0[t] = lds.Rpos[df * 8 + q];
+        R.f1[t] = lds.Rpos[df * 8 + 4 + q];
+        R.fg[t] = q < 3 ? lds.Rneg[df * 4 + q] : 0.0;
+    }
+    R.ng0[0] = lds.Rneg[0]; R.ng0[1] = lds.Rneg[1]; R.ng0[2] = lds.Rneg[2];
+}
+
 /*
  * DiseaseSpread::eval (covid.h:325-496) of the parameter vector W.xp for the chain of this WAVE.  Every lane
  * returns the same loglike.  Same operations on every accumulator, in the same order, as eval_model<T, true>.
  */
 __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsView& lds, const WaveSlice& W,
-                                                  const LaneScalars& lp, unsigned lane, WorkCount& work, int ldsRows) {
+                                                  const LaneScalars& lp, unsigned lane, WorkCount& work, int ldsRows,
+                                                  const WaveRows& BR, PhaseClock& pc) {
     const int md = M.md;
     const int horizon = M.simDays;
     const int q = (int)(lane >> 4), n = (int)(lane & 15);     /* MFMA result: rows q, q+4 (, q+8, q+12) of column n */
@@ -100,86 +133,127 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
         int keLo = 0x7fffffff, keHi = -1;                           /* source days with a capacity correction */
         for (int k = (int)lane; k < W.histLen; k += MCMC_WAVE) { W.hn[k] = 0.0; W.he[k] = 0.0; }
         wave_sync();
+        pc.stamp(PH_SETUP);
         double ncur = 1.0;                                          /* patient zero on day s, covid.h:339 */
         double* ds = shift == 1 ? W.d1 : W.d0;
 
 #pragma unroll 1
-        for (int j0 = s; j0 < horizon; j0 += MCMC_WV_T) {
+        for (int j0 = s; j0 < horizon; j0 += MCMC_WV_B) {
             double4_t c = {0.0, 0.0, 0.0, 0.0};
-            /* ---------- phase A: sources k < j0 (entries >= j0 of the history are still zero) */
+            /* what the block's days need besides the sums, one day per lane (every row group q repeats it):
+             * capacity of the day and pcf * smoothbehavior (covid.h:432-454), fetched per day with v_readlane */
+            double capMine[2], tbMine[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int iMine = min(j0 + MCMC_WV_T * h + n, M.simPad - 1);
+                capMine[h] = lds.capacity[iMine];
+                const int sgMine = lds.seg[iMine];
+                const double pcfMine = sgMine >= 0 ? xdisc[max(sgMine, 0)] : 1.0;
+                double smoothMine = 1.0;
+                if (iMine >= md) smoothMine = pcfMine * W.xp[min(max(iMine - md, 0), M.nB - 1)];
+                tbMine[h] = pcfMine * smoothMine;
+            }
+            /* ---------- phase A: sources k < j0 (entries >= j0 of the history are still zero).  Tile rows m < 8: the
+             * block's days 0..15 at lag L; rows m >= 8: its days 16..31, i.e. the same source day at lag L + 16 */
             if (j0 > s) {
                 const bool anyE = keHi >= keLo;
                 const int eLagLo = j0 - keHi, eLagHi = j0 + (MCMC_WV_T - 1) - keLo;
                 const int Lhi = j0 + (MCMC_WV_T - 1) - s;
+                const int Loff = (m >> 3) * MCMC_WV_T, col = m & 7;
                 const double* hnB = W.hn + MCMC_WV_HLO + j0 + n;       /* source day of lag L: j0 + n - L */
                 const double* heB = W.he + MCMC_WV_HLO + j0 + n;
+                /* operands of the NEXT group are requested before the current group's matrix instruction is
+                 * issued */
+                double aN = lds.Rpos[min(max(Lhi - kk, 0) + Loff, rowsM1) * 8 + col];
+                double bN = hnB[-(Lhi - kk)];
 #pragma unroll 1
                 for (int L0 = Lhi; L0 >= 1; L0 -= 4) {
+                    const double a = aN, b = bN;
+                    {
+                        const int Ln = L0 - 4 - kk;                  /* below lag 1 the history operand is zero anyway */
+                        aN = lds.Rpos[min(max(Ln, 0) + Loff, rowsM1) * 8 + col];
+                        bN = hnB[-max(Ln, -3)];
+                    }
                     if (!(anyE && L0 >= eLagLo && L0 - 3 <= eLagHi)) {
-                        const int L = L0 - kk;
-                        const double a = lds.Rpos[min(max(L, 0), rowsM1) * 8 + (m & 7)];
-                        const double b = hnB[-L];
+                        pc.count(PH_NCHUNK, 1);
                         c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
                     } else {
+                        pc.count(PH_NCHUNK_E, 1);
 #pragma unroll 1
                         for (int L = L0; L > L0 - 4 && L >= 1; --L) {
-                            const int Lr = min(L, rowsM1);
+                            const int Lr = min(L + Loff, rowsM1);
                             /* K slots: n_k R_c[L]; + e_k (deaths: the flat add() of covid.h:387-391, cut after
                              * traj.nDays lags like project()); - e_k x the three FromSerious curves; nothing */
-                            double a = 0.0, b = 0.0;
-                            if (kk == 0) { a = lds.Rpos[Lr * 8 + (m & 7)]; b = hnB[-L]; }
-                            else if (kk == 1) { a = (m == A_DEAD) ? lds.Rneg[Lr * 4 + 3] : 0.0; b = heB[-L]; }
-                            else if (kk == 2) { a = (m >= A_SER && m <= A_DEAD) ? lds.Rneg[Lr * 4 + (m - A_SER)] : 0.0; b = -heB[-L]; }
-                            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+                            double ae = 0.0, be = 0.0;
+                            if (kk == 0) { ae = lds.Rpos[Lr * 8 + col]; be = hnB[-L]; }
+                            else if (kk == 1) { ae = (col == A_DEAD) ? lds.Rneg[Lr * 4 + 3] : 0.0; be = heB[-L]; }
+                            else if (kk == 2) { ae = (col >= A_SER && col <= A_DEAD) ? lds.Rneg[Lr * 4 + (col - A_SER)] : 0.0; be = -heB[-L]; }
+                            c = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be, c, 0, 0, 0);
                         }
                     }
                 }
             }
-            /* ---------- phase B: the block's days in order.  c[0] = (MI, HI, INC, MILD)[q] of day n, c[1] = (SER, REC, DEAD, -)[q] */
+            pc.stamp(PH_CHUNKS);
+            /* ---------- phase B: the block's days in order.  c0 = (MI, HI, INC, MILD)[q] and c1 = (SER, REC, DEAD, -)[q] of
+             * day n; c2, c3 the same of day 16 + n */
+            double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
 #pragma unroll
-            for (int t = 0; t < MCMC_WV_T; ++t) {
+            for (int t = 0; t < MCMC_WV_B; ++t) {
                 const int i = j0 + t;
-                if (i >= horizon) break;
-                W.hn[MCMC_WV_HLO + i] = ncur;
-                /* today's new infections into today and the rest of the block (covid.h:403-410) */
-                if (n >= t) {
-                    const int d = n - t;
-                    c[0] = __builtin_fma(ncur, lds.Rpos[d * 8 + q], c[0]);
-                    c[1] = __builtin_fma(ncur, lds.Rpos[d * 8 + 4 + q], c[1]);     /* q = 3: the table's zero column */
-                }
-                const double vMI = readlane_f64(c[0], t), vHI = readlane_f64(c[0], 16 + t), vINC = readlane_f64(c[0], 32 + t),
-                             vMILD = readlane_f64(c[0], 48 + t);
-                double vSER = readlane_f64(c[1], t), vREC = readlane_f64(c[1], 16 + t), vDEAD = readlane_f64(c[1], 32 + t);
-                /* hospital capacity (covid.h:413-429) */
-                const double overCapacity = vSER * M.probICU - lds.capacity[i];
-                const double extraDeaths = M.probLethal * overCapacity;
-                if (__builtin_amdgcn_readfirstlane((extraDeaths > 0) ? 1 : 0)) {
-                    const double e = extraDeaths, ne = -extraDeaths;
-                    W.he[MCMC_WV_HLO + i] = e;
-                    keLo = min(keLo, i);
-                    keHi = max(keHi, i);
-                    if (n >= t && q < 3) {
-                        const int d = n - t;
-                        if (q == 2) c[1] = c[1] + e;
-                        c[1] = __builtin_fma(ne, lds.Rneg[d * 4 + q], c[1]);
+                if (i < horizon) {                                                  /* wave-uniform */
+                    const int u = t & (MCMC_WV_T - 1);
+                    const bool second = t >= MCMC_WV_T;
+                    if (lane == 0) W.hn[MCMC_WV_HLO + i] = ncur;
+                    /* today's new infections into today and the rest of the block (covid.h:403-410) */
+                    double va, vb;                                                  /* the half that holds today */
+                    if (!second) {
+                        c0 = __builtin_fma(ncur, BR.p0[u], c0);
+                        c1 = __builtin_fma(ncur, BR.p1[u], c1);
+                        c2 = __builtin_fma(ncur, BR.f0[u], c2);
+                        c3 = __builtin_fma(ncur, BR.f1[u], c3);
+                        va = c0; vb = c1;
+                    } else {
+                        c2 = __builtin_fma(ncur, BR.p0[u], c2);
+                        c3 = __builtin_fma(ncur, BR.p1[u], c3);
+                        va = c2; vb = c3;
+                    }
+                    const double vMI = readlane_f64(va, u), vHI = readlane_f64(va, 16 + u), vINC = readlane_f64(va, 32 + u),
+                                 vMILD = readlane_f64(va, 48 + u);
+                    double vSER = readlane_f64(vb, u), vREC = readlane_f64(vb, 16 + u), vDEAD = readlane_f64(vb, 32 + u);
+                    const double capT = readlane_f64(capMine[second ? 1 : 0], u), tbT = readlane_f64(tbMine[second ? 1 : 0], u);
+                    /* hospital capacity (covid.h:413-429).  Straight-line: without a correction e = +0, and adding
+                     * +0 or the product -0 * x changes no sum (none of them is ever -0) */
+                    const double overCapacity = vSER * M.probICU - capT;
+                    const double extraDeaths = M.probLethal * overCapacity;
+                    const bool hasE = extraDeaths > 0;
+                    const double e = hasE ? extraDeaths : 0.0, ne = -e;
+                    if (__builtin_amdgcn_readfirstlane(hasE ? 1 : 0)) {             /* off the critical path */
+                        if (lane == 0) W.he[MCMC_WV_HLO + i] = e;
+                        keLo = min(keLo, i);
+                        keHi = max(keHi, i);
+                    }
+                    const double eDead = (q == 2) ? e : 0.0;                        /* deaths: + e, then the projections */
+                    if (!second) {
+                        c1 = c1 + eDead;
+                        c1 = __builtin_fma(ne, BR.ng[u], c1);
+                        c3 = c3 + eDead;
+                        c3 = __builtin_fma(ne, BR.fg[u], c3);
+                    } else {
+                        c3 = c3 + eDead;
+                        c3 = __builtin_fma(ne, BR.ng[u], c3);
                     }
                     vDEAD = vDEAD + e;                                              /* today's own sums, the same operations */
-                    vSER = __builtin_fma(ne, lds.Rneg[0], vSER);
-                    vREC = __builtin_fma(ne, lds.Rneg[1], vREC);
-                    vDEAD = __builtin_fma(ne, lds.Rneg[2], vDEAD);
+                    vSER = __builtin_fma(ne, BR.ng0[0], vSER);
+                    vREC = __builtin_fma(ne, BR.ng0[1], vREC);
+                    vDEAD = __builtin_fma(ne, BR.ng0[2], vDEAD);
+                    /* tomorrow's new infections (covid.h:461-462); asymptomatic == mild buffer */
+                    const double nSus = M.pop - vINC - vMILD - vMILD - vSER - vREC - vDEAD;
+                    const double nnext = tbT * nSus / M.pop * (lp.betaMild * vMI + lp.betaHigh * vHI);
+                    if (lane == 0 && i >= md && i - md < M.nData) ds[i - md] = w * vDEAD;   /* covid.h:475,484 */
+                    ncur = nnext;
                 }
-                /* piecewise-constant factor and behaviour (covid.h:432-454) */
-                const int sg = lds.seg[i];
-                const double pcf = sg >= 0 ? xdisc[max(sg, 0)] : 1.0;
-                double smoothbehavior = 1.0;
-                if (i >= md) smoothbehavior = pcf * W.xp[min(max(i - md, 0), M.nB - 1)];
-                const double totalBehavior = pcf * smoothbehavior;
-                /* tomorrow's new infections (covid.h:461-462); asymptomatic == mild buffer */
-                const double nSus = M.pop - vINC - vMILD - vMILD - vSER - vREC - vDEAD;
-                const double nnext = totalBehavior * nSus / M.pop * (lp.betaMild * vMI + lp.betaHigh * vHI);
-                if (i >= md && i - md < M.nData) ds[i - md] = w * vDEAD;            /* covid.h:475,484 */
-                ncur = nnext;
             }
+            pc.stamp(PH_DAYS);
             wave_sync();
         }
         /* log-likelihood of this pass (covid.h:488-492): one term per lane, then the sum in day order */
@@ -194,6 +268,7 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
 #pragma unroll 8
         for (int i = 0; i < M.nData; ++i) loglike += W.terms[i];
         wave_sync();
+        pc.stamp(PH_LOGLIKE);
     }
     return loglike;
 }
@@ -360,7 +435,11 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, 
     work.exec = pairs_g[MCMC_WAVE];
     const double rungBeta = S.chainBeta ? S.chainBeta[flat] : 1.0;
     int slot = slot0;
+    WaveRows BR;
+    load_wave_rows(lds, lane, BR);
     wave_sync();
+    PhaseClock pc;
+    pc.start();
 
 #pragma unroll 1
     for (int g = 0; g < n_steps; ++g) {
@@ -392,8 +471,10 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, 
         }
         LaneScalars lp;
         double llpNew;
+        pc.stamp(PH_RECORD);
         const bool behChanged = propose_wave(M, rnd, W, lane, stepsize, lp, llpNew);
-        const double llm = eval_model_wave(M, lds, W, lp, lane, work, ldsRows);
+        pc.stamp(PH_PROPOSE);
+        const double llm = eval_model_wave(M, lds, W, lp, lane, work, ldsRows, BR, pc);
         double llp = 0.0;
         double delta = 0;                                           /* mcmc.h:604-606 */
         delta += -llModel + llm;
@@ -416,7 +497,9 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, 
             const double acceptRate = (double)nAccept / 20;
             stepsize *= rate2corr(acceptRate);
         }
+        pc.stamp(PH_ACCEPT);
     }
+    pc.flush(lane, (int)chain);
 
     for (int k = (int)lane; k < dim; k += MCMC_WAVE) xg[(size_t)k * MCMC_WAVE] = W.xc[k];
     if (lane == 0) {

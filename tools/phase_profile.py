@@ -12,7 +12,10 @@ regions = int(os.environ.get("MCMC_REGIONS", "0"))         # > 0: the multi-regi
 if regions:
     cfgs, R, xs, s = bench.build_region_workload(0, n, 1, 1, regions, int(os.environ.get("MCMC_REGION_DAYS", "500")))
 else:
-    cfg, R, xs, s = bench.build_workload(0, n, 1, 1, precision=precision)
+    cfg, R, xs, s = bench.build_workload(0, n, 1, 1, n_data=int(os.environ.get("MCMC_NDATA", "365")), precision=precision)
+    if os.environ.get("MCMC_MAPPING"):
+        s.set_mapping(os.environ["MCMC_MAPPING"])
+    print("mapping:", s.mapping())
 if adjust:
     s.run(0, 0, adjust, 1000000)
 s.step(16, 1.0, True)
@@ -26,7 +29,7 @@ print(f"{n * steps / dt / 1e6:.2f} M steps/s (stamped build), acceptance {s.acce
 counts = {k: ph.pop(k) for k in ("n_chunks", "n_chunks_e", "e_days", "e_hull")}
 slowest = ph.pop("slowest_wave")
 tot = sum(ph.values())
-waves = (n + 63) // 64
+waves = n if s.mapping() == "wave" else (n + 63) // 64
 for k, v in ph.items():
     print(f"{k:8s} {v / waves / steps:12.0f} cycles/wave/step  {100 * v / max(tot, 1):5.1f} %")
 print(f"total    {tot / waves / steps:12.0f} cycles/wave/step")

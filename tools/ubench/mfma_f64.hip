@@ -86,5 +86,25 @@ int main() {
         }
         printf("mfma_f64_16x16x4 x4 tiles, waves=%d: %.3f ms  %.2f TFLOP/s\n", waves, ms, 2.0 * 1024 * 4 * iters * (double)waves / ms / 1e9);
     }
+    // dependent chains: how long one wave waits for its own previous result (the small-ensemble kernel's phase A)
+    for (int waves : {1024}) {
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(rate<1>, dim3(waves), dim3(64), 0, 0, d, iters, 1.0000001, 0.9999999);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        printf("mfma_f64_16x16x4 x1 tile (dependent chain), waves=%d: %.3f ms  %.2f TFLOP/s  %.1f ns per instruction\n", waves, ms,
+               2.0 * 1024 * 1 * iters * (double)waves / ms / 1e9, ms * 1e6 / iters);
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(rate<2>, dim3(waves), dim3(64), 0, 0, d, iters, 1.0000001, 0.9999999);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        printf("mfma_f64_16x16x4 x2 tiles, waves=%d: %.3f ms  %.2f TFLOP/s  %.1f ns per instruction\n", waves, ms,
+               2.0 * 1024 * 2 * iters * (double)waves / ms / 1e9, ms * 1e6 / iters / 2);
+    }
     return bad_chain != 0;
 }
