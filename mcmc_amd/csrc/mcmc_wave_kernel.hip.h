@@ -39,16 +39,18 @@
 __host__ __device__ inline size_t wave_slice_doubles(const DevModel& M, int dim) {
     const size_t histLen = (size_t)M.simDays + MCMC_WV_HLO + MCMC_WV_HHI;
     const size_t terms = (size_t)(M.nData > M.nB ? M.nData : M.nB);
-    return 2 * histLen + 2 * (size_t)M.nData + terms + 2 * (size_t)dim;
+    return 4 * histLen + 2 * (size_t)M.nData + terms + 2 * (size_t)dim + MCMC_WAVE;
 }
-__host__ __device__ inline size_t wave_lds_bytes(const DevModel& M, int dim) {
-    return ((lds_bytes(M, false, MCMC_WV_T) + 7) / 8 + (size_t)MCMC_WAVES_PER_BLOCK * wave_slice_doubles(M, dim)) * sizeof(double);
+/* LDS of a workgroup of `waves` chains: the shared image of tables and series + one slice per wave */
+__host__ __device__ inline size_t wave_lds_bytes(const DevModel& M, int dim, int waves) {
+    return ((lds_bytes(M, false, MCMC_WV_T) + 7) / 8 + (size_t)waves * wave_slice_doubles(M, dim)) * sizeof(double);
 }
 
 /* the wave's slice */
 struct WaveSlice {
-    double* hn;        /* [histLen] infections per day, day k at hn[k + MCMC_WV_HLO] */
-    double* he;        /* [histLen] extra deaths per day                            */
+    double* hn[2];     /* [histLen] infections per day of either pass, day k at hn[p][k + MCMC_WV_HLO] */
+    double* he[2];     /* [histLen] extra deaths per day                            */
+    double* dummy;     /* [64] one slot per lane for the stores of the branch-free day loop that must not happen */
     double* d1;        /* [nData] weighted deaths of the first pass (shift 1)       */
     double* d0;        /* [nData] ... of the second                                 */
     double* terms;     /* [max(nData, nB)] per-day / per-node terms awaiting their ordered sum */
@@ -108,75 +110,104 @@ __device__ __forceinline__ void load_wave_rows(const LdsView& lds, unsigned lane
 /*
  * DiseaseSpread::eval (covid.h:325-496) of the parameter vector W.xp for the chain of this WAVE.  Every lane
  * returns the same loglike.  Same operations on every accumulator, in the same order, as eval_model<T, true>.
+ *
+ * The reference's two integer-shift passes (covid.h:335: first day start + 1, then start) are independent until
+ * their likelihood terms are summed, so they run here IN LOCKSTEP, block for block and day for day: pass index
+ * p = 0 is shift 1 (the first in the reference's order), p = 1 is shift 0.  Two independent matrix-instruction
+ * chains keep the matrix pipe at its throughput instead of one chain's latency (116 against 62 ns per
+ * instruction, tools/ubench/mfma_f64.hip), and the two sequential day chains fill each other's latency gaps.
+ * The day loop is branch-free for that reason (stores go to a per-lane dummy slot when they must not happen).
  */
 __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsView& lds, const WaveSlice& W,
                                                   const LaneScalars& lp, unsigned lane, WorkCount& work, int ldsRows,
                                                   const WaveRows& BR, PhaseClock& pc) {
     const int md = M.md;
     const int horizon = M.simDays;
-    const int q = (int)(lane >> 4), n = (int)(lane & 15);     /* MFMA result: rows q, q+4 (, q+8, q+12) of column n */
-    const int kk = q, m = n;                                   /* MFMA operands: A[m][kk], B[kk][n]                  */
+    const int q = (int)(lane >> 4), n = (int)(lane & 15);     /* MFMA result: rows q, q+4, q+8, q+12 of column n */
+    const int kk = q, m = n;                                   /* MFMA operands: A[m][kk], B[kk][n]               */
     const int rowsM1 = ldsRows - 1;
     const double* xdisc = W.xp + M.nB;
+    const bool lane0 = lane == 0;
+    double* const dummy = W.dummy + lane;                       /* where a store that must not happen goes */
 
-    double loglike = 0;                                             /* covid.h:329 */
     int start = (int)((double)md - lp.delay);                       /* covid.h:331 */
     const double frac = (double)md - lp.delay - (double)start;      /* covid.h:332 */
     start = min(max(start, 0), horizon);
     start = __builtin_amdgcn_readfirstlane(start);
     count_work(M, start, work);
 
-#pragma unroll 1
-    for (int shift = 1; shift >= 0; --shift) {                      /* covid.h:335 */
-        const double w = (double)(1 - shift) * (1.0 - frac) + (double)shift * frac; /* covid.h:333 */
-        const int s = min(start + shift, horizon);
-        int keLo = 0x7fffffff, keHi = -1;                           /* source days with a capacity correction */
-        for (int k = (int)lane; k < W.histLen; k += MCMC_WAVE) { W.hn[k] = 0.0; W.he[k] = 0.0; }
-        wave_sync();
-        pc.stamp(PH_SETUP);
-        double ncur = 1.0;                                          /* patient zero on day s, covid.h:339 */
-        double* ds = shift == 1 ? W.d1 : W.d0;
+    int sP[2];
+    double wP[2], ncur[2];
+    double* hnP[2] = {W.hn[0], W.hn[1]};
+    double* heP[2] = {W.he[0], W.he[1]};
+    double* dsP[2] = {W.d1, W.d0};
+    int keLo[2], keHi[2];                                           /* source days with a capacity correction */
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int shift = 1 - p;
+        wP[p] = (double)(1 - shift) * (1.0 - frac) + (double)shift * frac;      /* covid.h:333 */
+        sP[p] = min(start + shift, horizon);
+        ncur[p] = 1.0;                                              /* patient zero on day s, covid.h:339 */
+        keLo[p] = 0x7fffffff; keHi[p] = -1;
+    }
+    for (int k = (int)lane; k < W.histLen; k += MCMC_WAVE) {
+        W.hn[0][k] = 0.0; W.he[0][k] = 0.0; W.hn[1][k] = 0.0; W.he[1][k] = 0.0;
+    }
+    wave_sync();
+    pc.stamp(PH_SETUP);
 
 #pragma unroll 1
-        for (int j0 = s; j0 < horizon; j0 += MCMC_WV_B) {
-            double4_t c = {0.0, 0.0, 0.0, 0.0};
-            /* what the block's days need besides the sums, one day per lane (every row group q repeats it):
-             * capacity of the day and pcf * smoothbehavior (covid.h:432-454), fetched per day with v_readlane */
-            double capMine[2], tbMine[2];
+    for (int blk = 0; sP[1] + blk * MCMC_WV_B < horizon; ++blk) {
+        const int j0P[2] = {sP[0] + blk * MCMC_WV_B, sP[1] + blk * MCMC_WV_B};
+        double4_t c[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+        /* what the block's days need besides the sums, one day per lane (every row group q repeats it):
+         * capacity of the day and pcf * smoothbehavior (covid.h:432-454), fetched per day with v_readlane */
+        double capMine[2][2], tbMine[2][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int iMine = min(j0 + MCMC_WV_T * h + n, M.simPad - 1);
-                capMine[h] = lds.capacity[iMine];
+                const int iMine = min(j0P[p] + MCMC_WV_T * h + n, M.simPad - 1);
+                capMine[p][h] = lds.capacity[iMine];
                 const int sgMine = lds.seg[iMine];
                 const double pcfMine = sgMine >= 0 ? xdisc[max(sgMine, 0)] : 1.0;
                 double smoothMine = 1.0;
                 if (iMine >= md) smoothMine = pcfMine * W.xp[min(max(iMine - md, 0), M.nB - 1)];
-                tbMine[h] = pcfMine * smoothMine;
+                tbMine[p][h] = pcfMine * smoothMine;
             }
-            /* ---------- phase A: sources k < j0 (entries >= j0 of the history are still zero).  Tile rows m < 8: the
-             * block's days 0..15 at lag L; rows m >= 8: its days 16..31, i.e. the same source day at lag L + 16 */
-            if (j0 > s) {
-                const bool anyE = keHi >= keLo;
-                const int eLagLo = j0 - keHi, eLagHi = j0 + (MCMC_WV_T - 1) - keLo;
-                const int Lhi = j0 + (MCMC_WV_T - 1) - s;
-                const int Loff = (m >> 3) * MCMC_WV_T, col = m & 7;
-                const double* hnB = W.hn + MCMC_WV_HLO + j0 + n;       /* source day of lag L: j0 + n - L */
-                const double* heB = W.he + MCMC_WV_HLO + j0 + n;
-                /* operands of the NEXT group are requested before the current group's matrix instruction is
-                 * issued */
-                double aN = lds.Rpos[min(max(Lhi - kk, 0) + Loff, rowsM1) * 8 + col];
-                double bN = hnB[-(Lhi - kk)];
+        /* ---------- phase A: sources k < j0 (entries >= j0 of the history are still zero).  Tile rows m < 8: the
+         * block's days 0..15 at lag L; rows m >= 8: its days 16..31, i.e. the same source day at lag L + 16.  The
+         * table operand is the same for both passes, the history operand is each pass's own. */
+        if (blk > 0) {
+            const int Lhi = blk * MCMC_WV_B + (MCMC_WV_T - 1);
+            const int Loff = (m >> 3) * MCMC_WV_T, col = m & 7;
+            const double* hnB[2] = {hnP[0] + MCMC_WV_HLO + j0P[0] + n, hnP[1] + MCMC_WV_HLO + j0P[1] + n};   /* source day of lag L: j0 + n - L */
+            const double* heB[2] = {heP[0] + MCMC_WV_HLO + j0P[0] + n, heP[1] + MCMC_WV_HLO + j0P[1] + n};
+            bool anyE[2];
+            int eLagLo[2], eLagHi[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                anyE[p] = keHi[p] >= keLo[p];
+                eLagLo[p] = j0P[p] - keHi[p];
+                eLagHi[p] = j0P[p] + (MCMC_WV_T - 1) - keLo[p];
+            }
+            /* operands of the NEXT group are requested before the current group's matrix instructions are issued */
+            double aN = lds.Rpos[min(max(Lhi - kk, 0) + Loff, rowsM1) * 8 + col];
+            double bN[2] = {hnB[0][-(Lhi - kk)], hnB[1][-(Lhi - kk)]};
 #pragma unroll 1
-                for (int L0 = Lhi; L0 >= 1; L0 -= 4) {
-                    const double a = aN, b = bN;
-                    {
-                        const int Ln = L0 - 4 - kk;                  /* below lag 1 the history operand is zero anyway */
-                        aN = lds.Rpos[min(max(Ln, 0) + Loff, rowsM1) * 8 + col];
-                        bN = hnB[-max(Ln, -3)];
-                    }
-                    if (!(anyE && L0 >= eLagLo && L0 - 3 <= eLagHi)) {
+            for (int L0 = Lhi; L0 >= 1; L0 -= 4) {
+                const double a = aN, b[2] = {bN[0], bN[1]};
+                {
+                    const int Ln = L0 - 4 - kk;                      /* below lag 1 the history operand is zero anyway */
+                    aN = lds.Rpos[min(max(Ln, 0) + Loff, rowsM1) * 8 + col];
+                    bN[0] = hnB[0][-max(Ln, -3)];
+                    bN[1] = hnB[1][-max(Ln, -3)];
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    if (!(anyE[p] && L0 >= eLagLo[p] && L0 - 3 <= eLagHi[p])) {
                         pc.count(PH_NCHUNK, 1);
-                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+                        c[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[p], c[p], 0, 0, 0);
                     } else {
                         pc.count(PH_NCHUNK_E, 1);
 #pragma unroll 1
@@ -185,62 +216,71 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
                             /* K slots: n_k R_c[L]; + e_k (deaths: the flat add() of covid.h:387-391, cut after
                              * traj.nDays lags like project()); - e_k x the three FromSerious curves; nothing */
                             double ae = 0.0, be = 0.0;
-                            if (kk == 0) { ae = lds.Rpos[Lr * 8 + col]; be = hnB[-L]; }
-                            else if (kk == 1) { ae = (col == A_DEAD) ? lds.Rneg[Lr * 4 + 3] : 0.0; be = heB[-L]; }
-                            else if (kk == 2) { ae = (col >= A_SER && col <= A_DEAD) ? lds.Rneg[Lr * 4 + (col - A_SER)] : 0.0; be = -heB[-L]; }
-                            c = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be, c, 0, 0, 0);
+                            if (kk == 0) { ae = lds.Rpos[Lr * 8 + col]; be = hnB[p][-L]; }
+                            else if (kk == 1) { ae = (col == A_DEAD) ? lds.Rneg[Lr * 4 + 3] : 0.0; be = heB[p][-L]; }
+                            else if (kk == 2) { ae = (col >= A_SER && col <= A_DEAD) ? lds.Rneg[Lr * 4 + (col - A_SER)] : 0.0; be = -heB[p][-L]; }
+                            c[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be, c[p], 0, 0, 0);
                         }
                     }
                 }
             }
-            pc.stamp(PH_CHUNKS);
-            /* ---------- phase B: the block's days in order.  c0 = (MI, HI, INC, MILD)[q] and c1 = (SER, REC, DEAD, -)[q] of
-             * day n; c2, c3 the same of day 16 + n */
-            double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+        }
+        pc.stamp(PH_CHUNKS);
+        /* ---------- phase B: the block's days in order, both passes day for day.  cc[p][0] = (MI, HI, INC, MILD)[q] and
+         * cc[p][1] = (SER, REC, DEAD, -)[q] of day n; cc[p][2], cc[p][3] the same of day 16 + n */
+        double cc[2][4];
+        double keLoV[2], keHiV[2];                                   /* the correction range, carried as doubles: branch-free updates */
 #pragma unroll
-            for (int t = 0; t < MCMC_WV_B; ++t) {
-                const int i = j0 + t;
-                if (i < horizon) {                                                  /* wave-uniform */
-                    const int u = t & (MCMC_WV_T - 1);
-                    const bool second = t >= MCMC_WV_T;
-                    if (lane == 0) W.hn[MCMC_WV_HLO + i] = ncur;
+        for (int p = 0; p < 2; ++p) {
+            cc[p][0] = c[p][0]; cc[p][1] = c[p][1]; cc[p][2] = c[p][2]; cc[p][3] = c[p][3];
+            keLoV[p] = (double)keLo[p]; keHiV[p] = (double)keHi[p];
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half == 1 && !(j0P[1] + MCMC_WV_T < horizon)) break;        /* wave-uniform: nothing of the second half is simulated */
+#pragma unroll
+            for (int u = 0; u < MCMC_WV_T; ++u) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int i = j0P[p] + half * MCMC_WV_T + u;
+                    const bool live = i < horizon;                                  /* wave-uniform; days beyond compute garbage nobody reads */
+                    const bool st = lane0 && live;
+                    *(st ? hnP[p] + MCMC_WV_HLO + i : dummy) = ncur[p];
                     /* today's new infections into today and the rest of the block (covid.h:403-410) */
                     double va, vb;                                                  /* the half that holds today */
-                    if (!second) {
-                        c0 = __builtin_fma(ncur, BR.p0[u], c0);
-                        c1 = __builtin_fma(ncur, BR.p1[u], c1);
-                        c2 = __builtin_fma(ncur, BR.f0[u], c2);
-                        c3 = __builtin_fma(ncur, BR.f1[u], c3);
-                        va = c0; vb = c1;
+                    if (half == 0) {
+                        cc[p][0] = __builtin_fma(ncur[p], BR.p0[u], cc[p][0]);
+                        cc[p][1] = __builtin_fma(ncur[p], BR.p1[u], cc[p][1]);
+                        cc[p][2] = __builtin_fma(ncur[p], BR.f0[u], cc[p][2]);
+                        cc[p][3] = __builtin_fma(ncur[p], BR.f1[u], cc[p][3]);
+                        va = cc[p][0]; vb = cc[p][1];
                     } else {
-                        c2 = __builtin_fma(ncur, BR.p0[u], c2);
-                        c3 = __builtin_fma(ncur, BR.p1[u], c3);
-                        va = c2; vb = c3;
+                        cc[p][2] = __builtin_fma(ncur[p], BR.p0[u], cc[p][2]);
+                        cc[p][3] = __builtin_fma(ncur[p], BR.p1[u], cc[p][3]);
+                        va = cc[p][2]; vb = cc[p][3];
                     }
                     const double vMI = readlane_f64(va, u), vHI = readlane_f64(va, 16 + u), vINC = readlane_f64(va, 32 + u),
                                  vMILD = readlane_f64(va, 48 + u);
                     double vSER = readlane_f64(vb, u), vREC = readlane_f64(vb, 16 + u), vDEAD = readlane_f64(vb, 32 + u);
-                    const double capT = readlane_f64(capMine[second ? 1 : 0], u), tbT = readlane_f64(tbMine[second ? 1 : 0], u);
+                    const double capT = readlane_f64(capMine[p][half], u), tbT = readlane_f64(tbMine[p][half], u);
                     /* hospital capacity (covid.h:413-429).  Straight-line: without a correction e = +0, and adding
                      * +0 or the product -0 * x changes no sum (none of them is ever -0) */
                     const double overCapacity = vSER * M.probICU - capT;
                     const double extraDeaths = M.probLethal * overCapacity;
                     const bool hasE = extraDeaths > 0;
                     const double e = hasE ? extraDeaths : 0.0, ne = -e;
-                    if (__builtin_amdgcn_readfirstlane(hasE ? 1 : 0)) {             /* off the critical path */
-                        if (lane == 0) W.he[MCMC_WV_HLO + i] = e;
-                        keLo = min(keLo, i);
-                        keHi = max(keHi, i);
-                    }
+                    *(st ? heP[p] + MCMC_WV_HLO + i : dummy) = e;
+                    keLoV[p] = (hasE && live) ? fmin(keLoV[p], (double)i) : keLoV[p];
+                    keHiV[p] = (hasE && live) ? fmax(keHiV[p], (double)i) : keHiV[p];
                     const double eDead = (q == 2) ? e : 0.0;                        /* deaths: + e, then the projections */
-                    if (!second) {
-                        c1 = c1 + eDead;
-                        c1 = __builtin_fma(ne, BR.ng[u], c1);
-                        c3 = c3 + eDead;
-                        c3 = __builtin_fma(ne, BR.fg[u], c3);
+                    if (half == 0) {
+                        cc[p][1] = cc[p][1] + eDead;
+                        cc[p][1] = __builtin_fma(ne, BR.ng[u], cc[p][1]);
+                        cc[p][3] = cc[p][3] + eDead;
+                        cc[p][3] = __builtin_fma(ne, BR.fg[u], cc[p][3]);
                     } else {
-                        c3 = c3 + eDead;
-                        c3 = __builtin_fma(ne, BR.ng[u], c3);
+                        cc[p][3] = cc[p][3] + eDead;
+                        cc[p][3] = __builtin_fma(ne, BR.ng[u], cc[p][3]);
                     }
                     vDEAD = vDEAD + e;                                              /* today's own sums, the same operations */
                     vSER = __builtin_fma(ne, BR.ng0[0], vSER);
@@ -249,18 +289,29 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
                     /* tomorrow's new infections (covid.h:461-462); asymptomatic == mild buffer */
                     const double nSus = M.pop - vINC - vMILD - vMILD - vSER - vREC - vDEAD;
                     const double nnext = tbT * nSus / M.pop * (lp.betaMild * vMI + lp.betaHigh * vHI);
-                    if (lane == 0 && i >= md && i - md < M.nData) ds[i - md] = w * vDEAD;   /* covid.h:475,484 */
-                    ncur = nnext;
+                    const bool stD = st && i >= md && i - md < M.nData;
+                    *(stD ? dsP[p] + (i - md) : dummy) = wP[p] * vDEAD;              /* covid.h:475,484 */
+                    ncur[p] = nnext;
                 }
             }
-            pc.stamp(PH_DAYS);
-            wave_sync();
         }
-        /* log-likelihood of this pass (covid.h:488-492): one term per lane, then the sum in day order */
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            keLo[p] = __builtin_amdgcn_readfirstlane((int)keLoV[p]);
+            keHi[p] = __builtin_amdgcn_readfirstlane((int)keHiV[p]);
+        }
+        pc.stamp(PH_DAYS);
         wave_sync();
+    }
+    /* log-likelihood (covid.h:488-492): the first pass's terms, then the second's, one term per lane, each pass summed
+     * in day order onto the same sum */
+    double loglike = 0;                                             /* covid.h:329 */
+#pragma unroll 1
+    for (int p = 0; p < 2; ++p) {
+        const double w = uniform_f64(wP[p]);
         for (int i = (int)lane; i < M.nData; i += MCMC_WAVE) {
             double dv = W.d1[i];
-            if (shift == 0) dv = dv + W.d0[i];
+            if (p == 1) dv = dv + W.d0[i];
             const double delta = dv - lds.deaths[i];
             W.terms[i] = w * (-0.5 * delta * delta / lds.sigma2[i]);
         }
@@ -268,8 +319,8 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
 #pragma unroll 8
         for (int i = 0; i < M.nData; ++i) loglike += W.terms[i];
         wave_sync();
-        pc.stamp(PH_LOGLIKE);
     }
+    pc.stamp(PH_LOGLIKE);
     return loglike;
 }
 
@@ -398,7 +449,8 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, 
     const int ldsRows = lds_rows(M, false, MCMC_WV_T);
     const unsigned lane = threadIdx.x & (MCMC_WAVE - 1);
     const int waveInBlock = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / MCMC_WAVE));
-    const long long chain = (long long)blockIdx.x * MCMC_WAVES_PER_BLOCK + waveInBlock;
+    const int wavesPerBlock = (int)(blockDim.x / MCMC_WAVE);       /* 4, or fewer where the series leaves LDS for fewer slices */
+    const long long chain = (long long)blockIdx.x * wavesPerBlock + waveInBlock;
     if (chain >= S.nChains) return;
     const int tile = (int)(chain / MCMC_WAVE);
     const int lit = (int)(chain % MCMC_WAVE);                       /* the chain's lane in the tile-major arrays */
@@ -408,8 +460,11 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, 
     W.histLen = M.simDays + MCMC_WV_HLO + MCMC_WV_HHI;
     {
         double* p = lds_raw + (lds_bytes(M, false, MCMC_WV_T) + 7) / 8 + (size_t)waveInBlock * wave_slice_doubles(M, dim);
-        W.hn = p; p += W.histLen;
-        W.he = p; p += W.histLen;
+        W.hn[0] = p; p += W.histLen;
+        W.hn[1] = p; p += W.histLen;
+        W.he[0] = p; p += W.histLen;
+        W.he[1] = p; p += W.histLen;
+        W.dummy = p; p += MCMC_WAVE;
         W.d1 = p; p += M.nData;
         W.d0 = p; p += M.nData;
         W.terms = p; p += (M.nData > M.nB ? M.nData : M.nB);

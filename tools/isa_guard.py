@@ -13,7 +13,7 @@ def analyse(workdir):
     src = os.path.join(ROOT, "mcmc_amd", "csrc", "mcmc_hip.hip")
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "mcmc_amd", "csrc"), "-DMCMC_T=8",
-           "-Wno-unused-function", "-save-temps", "-c", src, "-o", os.path.join(workdir, "x.o")]
+           "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form", "-save-temps", "-c", src, "-o", os.path.join(workdir, "x.o")]
     subprocess.run(cmd, cwd=workdir, check=True, capture_output=True)
     asm = open(os.path.join(workdir, "mcmc_hip-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     out = {}
