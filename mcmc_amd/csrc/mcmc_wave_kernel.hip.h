@@ -70,6 +70,7 @@ __device__ __forceinline__ double readlane_f64(double v, int srcLane) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double both_f64(double lo, double hi, bool hiHalf) { return hiHalf ? hi : lo; }
 __device__ __forceinline__ double uniform_f64(double v) {
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
     const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
@@ -127,7 +128,6 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
     const int kk = q, m = n;                                   /* MFMA operands: A[m][kk], B[kk][n]               */
     const int rowsM1 = ldsRows - 1;
     const double* xdisc = W.xp + M.nB;
-    const bool lane0 = lane == 0;
     double* const dummy = W.dummy + lane;                       /* where a store that must not happen goes */
 
     int start = (int)((double)md - lp.delay);                       /* covid.h:331 */
@@ -136,20 +136,25 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
     start = __builtin_amdgcn_readfirstlane(start);
     count_work(M, start, work);
 
+    const bool hiHalf = lane >= 32;                              /* phase B: which pass's day arithmetic the lane carries */
     int sP[2];
-    double wP[2], ncur[2];
+    double wP[2], ncurS[2];                                       /* n of the current day of either pass, the same in every lane */
+    double ncurB = 1.0;                                           /* ... and as the lanes of the day chain hold it */
     double* hnP[2] = {W.hn[0], W.hn[1]};
     double* heP[2] = {W.he[0], W.he[1]};
-    double* dsP[2] = {W.d1, W.d0};
     int keLo[2], keHi[2];                                           /* source days with a capacity correction */
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int shift = 1 - p;
         wP[p] = (double)(1 - shift) * (1.0 - frac) + (double)shift * frac;      /* covid.h:333 */
         sP[p] = min(start + shift, horizon);
-        ncur[p] = 1.0;                                              /* patient zero on day s, covid.h:339 */
+        ncurS[p] = 1.0;                                             /* patient zero on day s, covid.h:339 */
         keLo[p] = 0x7fffffff; keHi[p] = -1;
     }
+    double* const hnDst = (hiHalf ? W.hn[1] : W.hn[0]) + MCMC_WV_HLO;
+    double* const heDst = (hiHalf ? W.he[1] : W.he[0]) + MCMC_WV_HLO;
+    double* const dsDst = hiHalf ? W.d0 : W.d1;
+    const double wBoth = hiHalf ? wP[1] : wP[0];
     for (int k = (int)lane; k < W.histLen; k += MCMC_WAVE) {
         W.hn[0][k] = 0.0; W.he[0][k] = 0.0; W.hn[1][k] = 0.0; W.he[1][k] = 0.0;
     }
@@ -159,146 +164,164 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
 #pragma unroll 1
     for (int blk = 0; sP[1] + blk * MCMC_WV_B < horizon; ++blk) {
         const int j0P[2] = {sP[0] + blk * MCMC_WV_B, sP[1] + blk * MCMC_WV_B};
-        double4_t c[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-        /* what the block's days need besides the sums, one day per lane (every row group q repeats it):
-         * capacity of the day and pcf * smoothbehavior (covid.h:432-454), fetched per day with v_readlane */
-        double capMine[2][2], tbMine[2][2];
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int iMine = min(j0P[p] + MCMC_WV_T * h + n, M.simPad - 1);
-                capMine[p][h] = lds.capacity[iMine];
-                const int sgMine = lds.seg[iMine];
-                const double pcfMine = sgMine >= 0 ? xdisc[max(sgMine, 0)] : 1.0;
-                double smoothMine = 1.0;
-                if (iMine >= md) smoothMine = pcfMine * W.xp[min(max(iMine - md, 0), M.nB - 1)];
-                tbMine[p][h] = pcfMine * smoothMine;
-            }
         /* ---------- phase A: sources k < j0 (entries >= j0 of the history are still zero).  Tile rows m < 8: the
          * block's days 0..15 at lag L; rows m >= 8: its days 16..31, i.e. the same source day at lag L + 16.  The
-         * table operand is the same for both passes, the history operand is each pass's own. */
+         * table operand is the same for both passes, the history operand is each pass's own.  Lag groups whose
+         * source days carry corrections in EITHER pass form one range of lags (a correction of zero changes
+         * nothing), so the groups split into three runs -- plain, with corrections, plain -- each a tight loop
+         * of its own with both tiles in fixed registers. */
+        double4_t c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
         if (blk > 0) {
             const int Lhi = blk * MCMC_WV_B + (MCMC_WV_T - 1);
             const int Loff = (m >> 3) * MCMC_WV_T, col = m & 7;
-            const double* hnB[2] = {hnP[0] + MCMC_WV_HLO + j0P[0] + n, hnP[1] + MCMC_WV_HLO + j0P[1] + n};   /* source day of lag L: j0 + n - L */
-            const double* heB[2] = {heP[0] + MCMC_WV_HLO + j0P[0] + n, heP[1] + MCMC_WV_HLO + j0P[1] + n};
-            bool anyE[2];
-            int eLagLo[2], eLagHi[2];
+            const double* hnB0 = hnP[0] + MCMC_WV_HLO + j0P[0] + n;   /* source day of lag L: j0 + n - L */
+            const double* hnB1 = hnP[1] + MCMC_WV_HLO + j0P[1] + n;
+            int eLo = 0x7fffffff, eHi = -1;                          /* the lags with corrections, both passes */
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                anyE[p] = keHi[p] >= keLo[p];
-                eLagLo[p] = j0P[p] - keHi[p];
-                eLagHi[p] = j0P[p] + (MCMC_WV_T - 1) - keLo[p];
-            }
-            /* operands of the NEXT group are requested before the current group's matrix instructions are issued */
-            double aN = lds.Rpos[min(max(Lhi - kk, 0) + Loff, rowsM1) * 8 + col];
-            double bN[2] = {hnB[0][-(Lhi - kk)], hnB[1][-(Lhi - kk)]};
+            for (int p = 0; p < 2; ++p)
+                if (keHi[p] >= keLo[p]) {
+                    eLo = min(eLo, j0P[p] - keHi[p]);
+                    eHi = max(eHi, j0P[p] + (MCMC_WV_T - 1) - keLo[p]);
+                }
+            const bool anyE = eHi >= eLo && eHi >= 1;
+            int L0 = Lhi;
+            auto plain_run = [&](int stop) {                         /* the groups with L0 >= stop */
+                if (L0 < stop) return;
+                /* operands of the NEXT group are requested before the current group's matrix instructions are issued */
+                double aN = lds.Rpos[min(max(L0 - kk, 0) + Loff, rowsM1) * 8 + col];
+                double bN0 = hnB0[-(L0 - kk)], bN1 = hnB1[-(L0 - kk)];
 #pragma unroll 1
-            for (int L0 = Lhi; L0 >= 1; L0 -= 4) {
-                const double a = aN, b[2] = {bN[0], bN[1]};
-                {
+                for (; L0 >= stop; L0 -= 4) {
+                    const double a = aN, b0 = bN0, b1 = bN1;
                     const int Ln = L0 - 4 - kk;                      /* below lag 1 the history operand is zero anyway */
                     aN = lds.Rpos[min(max(Ln, 0) + Loff, rowsM1) * 8 + col];
-                    bN[0] = hnB[0][-max(Ln, -3)];
-                    bN[1] = hnB[1][-max(Ln, -3)];
+                    bN0 = hnB0[-max(Ln, -3)];
+                    bN1 = hnB1[-max(Ln, -3)];
+                    pc.count(PH_NCHUNK, 2);
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, c1, 0, 0, 0);
                 }
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    if (!(anyE[p] && L0 >= eLagLo[p] && L0 - 3 <= eLagHi[p])) {
-                        pc.count(PH_NCHUNK, 1);
-                        c[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[p], c[p], 0, 0, 0);
-                    } else {
-                        pc.count(PH_NCHUNK_E, 1);
+            };
+            plain_run(anyE ? max(eHi + 4, 1) : 1);                   /* a plain group has L0 - 3 > eHi */
+            if (anyE) {
+                /* one lag per matrix instruction, the K slots holding the source day's three operations in the
+                 * reference's order: n_k R_c[L]; + e_k (deaths: the flat add() of covid.h:387-391, cut after
+                 * traj.nDays lags like project()); - e_k x the three FromSerious curves; nothing.  What a lane
+                 * feeds depends on its slot only: */
+                const double* eTab = kk == 0 ? lds.Rpos : lds.Rneg;
+                const int eStride = kk == 0 ? 8 : 4;
+                const int eOff = kk == 0 ? col : kk == 1 ? 3 : min(max(col - A_SER, 0), 2);
+                const bool eValid = kk == 0 || (kk == 1 && col == A_DEAD) || (kk == 2 && col >= A_SER && col <= A_DEAD);
+                const double* eH0 = (kk == 0 ? hnP[0] : heP[0]) + MCMC_WV_HLO + j0P[0] + n;
+                const double* eH1 = (kk == 0 ? hnP[1] : heP[1]) + MCMC_WV_HLO + j0P[1] + n;
+                const int Ltop = L0;
+                const int stop = max(eLo, 1);
+                while (L0 >= stop) L0 -= 4;                           /* the groups of this run */
+                const int Lbot = max(L0 + 1, 1);
+                pc.count(PH_NCHUNK_E, 2 * max(Ltop - Lbot + 1, 0));
 #pragma unroll 1
-                        for (int L = L0; L > L0 - 4 && L >= 1; --L) {
-                            const int Lr = min(L + Loff, rowsM1);
-                            /* K slots: n_k R_c[L]; + e_k (deaths: the flat add() of covid.h:387-391, cut after
-                             * traj.nDays lags like project()); - e_k x the three FromSerious curves; nothing */
-                            double ae = 0.0, be = 0.0;
-                            if (kk == 0) { ae = lds.Rpos[Lr * 8 + col]; be = hnB[p][-L]; }
-                            else if (kk == 1) { ae = (col == A_DEAD) ? lds.Rneg[Lr * 4 + 3] : 0.0; be = heB[p][-L]; }
-                            else if (kk == 2) { ae = (col >= A_SER && col <= A_DEAD) ? lds.Rneg[Lr * 4 + (col - A_SER)] : 0.0; be = -heB[p][-L]; }
-                            c[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be, c[p], 0, 0, 0);
-                        }
-                    }
+                for (int L = Ltop; L >= Lbot; --L) {
+                    const int Lr = min(L + Loff, rowsM1);
+                    const double t = eTab[Lr * eStride + eOff];
+                    const double x0 = eH0[-L], x1 = eH1[-L];
+                    const double ae = eValid ? t : 0.0;
+                    const double be0 = kk == 3 ? 0.0 : (kk == 2 ? -x0 : x0), be1 = kk == 3 ? 0.0 : (kk == 2 ? -x1 : x1);
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be0, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be1, c1, 0, 0, 0);
                 }
+                plain_run(1);
             }
         }
         pc.stamp(PH_CHUNKS);
         /* ---------- phase B: the block's days in order, both passes day for day.  cc[p][0] = (MI, HI, INC, MILD)[q] and
-         * cc[p][1] = (SER, REC, DEAD, -)[q] of day n; cc[p][2], cc[p][3] the same of day 16 + n */
-        double cc[2][4];
-        double keLoV[2], keHiV[2];                                   /* the correction range, carried as doubles: branch-free updates */
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            cc[p][0] = c[p][0]; cc[p][1] = c[p][1]; cc[p][2] = c[p][2]; cc[p][3] = c[p][3];
-            keLoV[p] = (double)keLo[p]; keHiV[p] = (double)keHi[p];
-        }
+         * cc[p][1] = (SER, REC, DEAD, -)[q] of day n; cc[p][2], cc[p][3] the same of day 16 + n.  The day's scalar
+         * arithmetic is the same for both passes on different numbers: lanes 0..31 carry pass 0's, lanes 32..63
+         * pass 1's, so ONE sequential chain of operations serves both. */
+        double cc[2][4] = {{c0[0], c0[1], c0[2], c0[3]}, {c1[0], c1[1], c1[2], c1[3]}};
+        double keLoB = hiHalf ? (double)keLo[1] : (double)keLo[0], keHiB = hiHalf ? (double)keHi[1] : (double)keHi[0];
+        const int j0B = hiHalf ? j0P[1] : j0P[0];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (half == 1 && !(j0P[1] + MCMC_WV_T < horizon)) break;        /* wave-uniform: nothing of the second half is simulated */
+            /* what the days need besides the sums, the lane's own pass: capacity and pcf * smoothbehavior (covid.h:432-454) */
+            double capB[MCMC_WV_T], tbB[MCMC_WV_T];
 #pragma unroll
             for (int u = 0; u < MCMC_WV_T; ++u) {
+                const int iB = min(j0B + half * MCMC_WV_T + u, M.simPad - 1);
+                capB[u] = lds.capacity[iB];
+                const int sg = lds.seg[iB];
+                const double pcf = sg >= 0 ? xdisc[max(sg, 0)] : 1.0;
+                double smoothbehavior = 1.0;
+                if (iB >= md) smoothbehavior = pcf * W.xp[min(max(iB - md, 0), M.nB - 1)];
+                tbB[u] = pcf * smoothbehavior;
+            }
+#pragma unroll
+            for (int u = 0; u < MCMC_WV_T; ++u) {
+                const int iB = j0B + half * MCMC_WV_T + u;                          /* the lane's pass's day */
+                const bool writer = (lane & 31) == 0 && iB < horizon;               /* days beyond compute garbage nobody reads */
+                *(writer ? hnDst + iB : dummy) = ncurB;
+                /* today's new infections into today and the rest of the block (covid.h:403-410) */
+                double va[2], vb[2];                                                /* the half that holds today */
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    const int i = j0P[p] + half * MCMC_WV_T + u;
-                    const bool live = i < horizon;                                  /* wave-uniform; days beyond compute garbage nobody reads */
-                    const bool st = lane0 && live;
-                    *(st ? hnP[p] + MCMC_WV_HLO + i : dummy) = ncur[p];
-                    /* today's new infections into today and the rest of the block (covid.h:403-410) */
-                    double va, vb;                                                  /* the half that holds today */
                     if (half == 0) {
-                        cc[p][0] = __builtin_fma(ncur[p], BR.p0[u], cc[p][0]);
-                        cc[p][1] = __builtin_fma(ncur[p], BR.p1[u], cc[p][1]);
-                        cc[p][2] = __builtin_fma(ncur[p], BR.f0[u], cc[p][2]);
-                        cc[p][3] = __builtin_fma(ncur[p], BR.f1[u], cc[p][3]);
-                        va = cc[p][0]; vb = cc[p][1];
+                        cc[p][0] = __builtin_fma(ncurS[p], BR.p0[u], cc[p][0]);
+                        cc[p][1] = __builtin_fma(ncurS[p], BR.p1[u], cc[p][1]);
+                        cc[p][2] = __builtin_fma(ncurS[p], BR.f0[u], cc[p][2]);
+                        cc[p][3] = __builtin_fma(ncurS[p], BR.f1[u], cc[p][3]);
+                        va[p] = cc[p][0]; vb[p] = cc[p][1];
                     } else {
-                        cc[p][2] = __builtin_fma(ncur[p], BR.p0[u], cc[p][2]);
-                        cc[p][3] = __builtin_fma(ncur[p], BR.p1[u], cc[p][3]);
-                        va = cc[p][2]; vb = cc[p][3];
+                        cc[p][2] = __builtin_fma(ncurS[p], BR.p0[u], cc[p][2]);
+                        cc[p][3] = __builtin_fma(ncurS[p], BR.p1[u], cc[p][3]);
+                        va[p] = cc[p][2]; vb[p] = cc[p][3];
                     }
-                    const double vMI = readlane_f64(va, u), vHI = readlane_f64(va, 16 + u), vINC = readlane_f64(va, 32 + u),
-                                 vMILD = readlane_f64(va, 48 + u);
-                    double vSER = readlane_f64(vb, u), vREC = readlane_f64(vb, 16 + u), vDEAD = readlane_f64(vb, 32 + u);
-                    const double capT = readlane_f64(capMine[p][half], u), tbT = readlane_f64(tbMine[p][half], u);
-                    /* hospital capacity (covid.h:413-429).  Straight-line: without a correction e = +0, and adding
-                     * +0 or the product -0 * x changes no sum (none of them is ever -0) */
-                    const double overCapacity = vSER * M.probICU - capT;
-                    const double extraDeaths = M.probLethal * overCapacity;
-                    const bool hasE = extraDeaths > 0;
-                    const double e = hasE ? extraDeaths : 0.0, ne = -e;
-                    *(st ? heP[p] + MCMC_WV_HLO + i : dummy) = e;
-                    keLoV[p] = (hasE && live) ? fmin(keLoV[p], (double)i) : keLoV[p];
-                    keHiV[p] = (hasE && live) ? fmax(keHiV[p], (double)i) : keHiV[p];
-                    const double eDead = (q == 2) ? e : 0.0;                        /* deaths: + e, then the projections */
+                }
+                /* both lanes' values are fetched, then selected: a select AROUND the (convergent) lane reads becomes branches */
+#define MCMC_BOTH(v, srcLane) both_f64(readlane_f64((v)[0], srcLane), readlane_f64((v)[1], srcLane), hiHalf)
+                const double vMI = MCMC_BOTH(va, u), vHI = MCMC_BOTH(va, 16 + u), vINC = MCMC_BOTH(va, 32 + u), vMILD = MCMC_BOTH(va, 48 + u);
+                double vSER = MCMC_BOTH(vb, u), vREC = MCMC_BOTH(vb, 16 + u), vDEAD = MCMC_BOTH(vb, 32 + u);
+#undef MCMC_BOTH
+                /* hospital capacity (covid.h:413-429).  Straight-line: without a correction e = +0, and adding
+                 * +0 or the product -0 * x changes no sum (none of them is ever -0) */
+                const double overCapacity = vSER * M.probICU - capB[u];
+                const double extraDeaths = M.probLethal * overCapacity;
+                const bool hasE = extraDeaths > 0;
+                const double e = hasE ? extraDeaths : 0.0, ne = -e;
+                *(writer ? heDst + iB : dummy) = e;
+                keLoB = (hasE && iB < horizon) ? fmin(keLoB, (double)iB) : keLoB;
+                keHiB = (hasE && iB < horizon) ? fmax(keHiB, (double)iB) : keHiB;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {                                       /* the later days' sums: + e (deaths), then the projections */
+                    const double eS = readlane_f64(e, 32 * p);
+                    const double eDead = (q == 2) ? eS : 0.0;
                     if (half == 0) {
                         cc[p][1] = cc[p][1] + eDead;
-                        cc[p][1] = __builtin_fma(ne, BR.ng[u], cc[p][1]);
+                        cc[p][1] = __builtin_fma(-eS, BR.ng[u], cc[p][1]);
                         cc[p][3] = cc[p][3] + eDead;
-                        cc[p][3] = __builtin_fma(ne, BR.fg[u], cc[p][3]);
+                        cc[p][3] = __builtin_fma(-eS, BR.fg[u], cc[p][3]);
                     } else {
                         cc[p][3] = cc[p][3] + eDead;
-                        cc[p][3] = __builtin_fma(ne, BR.ng[u], cc[p][3]);
+                        cc[p][3] = __builtin_fma(-eS, BR.ng[u], cc[p][3]);
                     }
-                    vDEAD = vDEAD + e;                                              /* today's own sums, the same operations */
-                    vSER = __builtin_fma(ne, BR.ng0[0], vSER);
-                    vREC = __builtin_fma(ne, BR.ng0[1], vREC);
-                    vDEAD = __builtin_fma(ne, BR.ng0[2], vDEAD);
-                    /* tomorrow's new infections (covid.h:461-462); asymptomatic == mild buffer */
-                    const double nSus = M.pop - vINC - vMILD - vMILD - vSER - vREC - vDEAD;
-                    const double nnext = tbT * nSus / M.pop * (lp.betaMild * vMI + lp.betaHigh * vHI);
-                    const bool stD = st && i >= md && i - md < M.nData;
-                    *(stD ? dsP[p] + (i - md) : dummy) = wP[p] * vDEAD;              /* covid.h:475,484 */
-                    ncur[p] = nnext;
                 }
+                vDEAD = vDEAD + e;                                                  /* today's own sums, the same operations */
+                vSER = __builtin_fma(ne, BR.ng0[0], vSER);
+                vREC = __builtin_fma(ne, BR.ng0[1], vREC);
+                vDEAD = __builtin_fma(ne, BR.ng0[2], vDEAD);
+                /* tomorrow's new infections (covid.h:461-462); asymptomatic == mild buffer */
+                const double nSus = M.pop - vINC - vMILD - vMILD - vSER - vREC - vDEAD;
+                const double nnext = tbB[u] * nSus / M.pop * (lp.betaMild * vMI + lp.betaHigh * vHI);
+                const bool stD = writer && iB >= md && iB - md < M.nData;
+                *(stD ? dsDst + (iB - md) : dummy) = wBoth * vDEAD;                 /* covid.h:475,484 */
+                ncurB = nnext;
+                ncurS[0] = readlane_f64(nnext, 0);
+                ncurS[1] = readlane_f64(nnext, 32);
             }
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            keLo[p] = __builtin_amdgcn_readfirstlane((int)keLoV[p]);
-            keHi[p] = __builtin_amdgcn_readfirstlane((int)keHiV[p]);
+            keLo[p] = (int)readlane_f64(keLoB, 32 * p);
+            keHi[p] = (int)readlane_f64(keHiB, 32 * p);
         }
         pc.stamp(PH_DAYS);
         wave_sync();
