@@ -33,13 +33,12 @@
 
 #define MCMC_WV_T 16          /* the 16 columns of the MFMA tile: days per HALF block */
 #define MCMC_WV_B 32          /* days per block: rows 0..6 of the tile hold the block's days 0..15, rows 8..14 its days 16..31 */
-#define MCMC_WV_HLO 24        /* zero history entries kept below day 0 (phase A reads down to s - 15) */
-#define MCMC_WV_HHI 40        /* ... and above the simulated horizon (phase A reads up to j0 + 18, as zeros; j0 <= horizon - 1) */
+#define MCMC_WV_HLO 16        /* zero history entries kept below day 0 (phase A reads down to s - 15) */
+#define MCMC_WV_HHI 20        /* ... and above the simulated horizon (phase A reads up to j0 + 18, as zeros; j0 <= horizon) */
 
 __host__ __device__ inline size_t wave_slice_doubles(const DevModel& M, int dim) {
     const size_t histLen = (size_t)M.simDays + MCMC_WV_HLO + MCMC_WV_HHI;
-    const size_t terms = (size_t)(M.nData > M.nB ? M.nData : M.nB);
-    return 4 * histLen + 2 * (size_t)M.nData + terms + 2 * (size_t)dim + MCMC_WAVE;
+    return 4 * histLen + 2 * (size_t)M.nData + 2 * (size_t)dim + MCMC_WAVE;
 }
 /* LDS of a workgroup of `waves` chains: the shared image of tables and series + one slice per wave */
 __host__ __device__ inline size_t wave_lds_bytes(const DevModel& M, int dim, int waves) {
@@ -53,7 +52,8 @@ struct WaveSlice {
     double* dummy;     /* [64] one slot per lane for the stores of the branch-free day loop that must not happen */
     double* d1;        /* [nData] weighted deaths of the first pass (shift 1)       */
     double* d0;        /* [nData] ... of the second                                 */
-    double* terms;     /* [max(nData, nB)] per-day / per-node terms awaiting their ordered sum */
+    double* terms;     /* [max(nData, nB)] per-day / per-node terms awaiting their ordered sum: the room of he[0], which is
+                          dead while the prior's terms (before the evaluation) and the likelihood's (after its days) exist */
     double* xc;        /* [dim] current parameter vector                            */
     double* xp;        /* [dim] proposal                                            */
     int histLen;
@@ -490,7 +490,7 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, 
         W.dummy = p; p += MCMC_WAVE;
         W.d1 = p; p += M.nData;
         W.d0 = p; p += M.nData;
-        W.terms = p; p += (M.nData > M.nB ? M.nData : M.nB);
+        W.terms = W.he[0];                 /* histLen = simDays + 36 > nData, nB */
         W.xc = p; p += dim;
         W.xp = p;
     }
