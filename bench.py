@@ -211,7 +211,7 @@ def toy_ess_leg(device, n_chains, threads):
     X_ros = np.stack([xr, xr ** 2 + np.sqrt(0.1) * rs.standard_normal(n_chains)], axis=1)
     # name, starts, (nSamples, nBurnin, nAdjust, thinning), difficulty, scalars of the ESS
     for name, X, sched, diff, k_use in [("mylike1", np.ones((n_chains, 3)), (10000, 2000, 500, 5), 1.0, 3),
-                                         ("rosenbrock", X_ros, (60000, 20000, 500, 20), 100.0, 2)]:
+                                         ("rosenbrock", X_ros, (600000, 100000, 500, 200), 100.0, 2)]:
         ns, nb, na, th = sched
         steps_per_chain = 20 * na + ns
         H.toy_run(name, X[:64], 10, 0, 1, 1, difficulty=diff, first_chain_id=1, device=device, record=False)   # module load
@@ -487,9 +487,10 @@ def main():
                        # one chain per lane: how much of the chip this ensemble can occupy at all
                        "occupancy": {"waves_per_gpu": n_waves, "simds_per_gpu": n_simd, "frac": min(1.0, n_waves / n_simd)},
                        "size": cfg["size"], "fp_contract": "fma" if args.contract else "strict",
-                       "fp_contract_models": ("a -march=native build of the reference (enoki_set_native_flags, CMakeLists.txt:98) "
-                                              "in which the compiler contracts project()'s `dest[d+k] += n*cumsum` (covid.h:384) "
-                                              "into one fused multiply-add; every other expression is a separate mul / add") if args.contract
+                       "fp_contract_models": ("the dominant effect of a contracting build of the reference (-march=native via "
+                                              "enoki_set_native_flags, CMakeLists.txt:98; gcc's default, clang >= 14): project()'s "
+                                              "`dest[d+k] += n*cumsum` (covid.h:384) is one fused multiply-add; every other expression is a "
+                                              "separate mul / add (covid.h:368,462,491 stay unfused: not any one compiler's exact output)") if args.contract
                                              else "the C++ source semantics: every projection term a multiply, then an add",
                        "adjust_iterations_before_timing": args.adjust, "start_spread": args.start_spread,
                        **({"ladder": {"temperatures": args.ladder, "t_max": args.ladder_tmax,

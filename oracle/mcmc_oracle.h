@@ -25,9 +25,12 @@
  * What is NOT pinned by any reference artefact ("parity unpinned"):
  *   - the covid model (DiseaseSpread::step / eval, SmoothnessPrior): the only recorded
  *     outputs (notebooks/covid*.ipynb) come from an older revision of covid.h with a
- *     different interface and capacity formula.  Restated expression by expression, with
- *     contraction off (the author's 2020 clang default); see the `contract` flag for the
- *     -ffp-contract=fast variant of the projection loop;
+ *     different interface and capacity formula.  Restated expression by expression.  The
+ *     reference pins no compiler, so two arithmetic modes exist ("Which
+ *     arithmetic"): contraction off = the C++ source semantics (also what the author's 2020
+ *     clang produced), and the `contract` flag = the projection statement covid.h:384 as one
+ *     fused multiply-add, the dominant effect of a contracting build (gcc's default, clang
+ *     >= 14) -- not any one compiler's exact output, since covid.h:368,462,491 stay unfused;
  *   - enoki::erfinv (restated as M. Giles' published single-precision polynomial); only
  *     used for the one-off response-table precompute, which is an explicit INPUT to both
  *     this oracle and the HIP path, so it cannot cause a mismatch;
