@@ -17,10 +17,13 @@
  *            (the workgroup's table image, the wave's own history).  Lags whose source day carries a hospital-
  *            capacity correction (covid.h:413-429) go one lag per MFMA, the K slots holding that source day's
  *            three operations in the reference's order: n_k * R_c[L], then + e_k (deaths), then - e_k * FromSerious[L].
- *   phase B  (the block's 16 days in order; the feedback n_{i+1} = f(buffers[i]) is sequential, covid.h:461-462)
- *            today's n_i goes into today's and the later days' accumulators from registers (one multiply-add per
- *            lane), the seven sums of today are fetched with v_readlane and the day's scalar arithmetic runs
- *            uniformly in every lane.
+ *   phase B  (the block's 32 days in order; the feedback n_{i+1} = f(buffers[i]) is sequential, covid.h:461-462)
+ *            the sums are transposed once per block (v_permlane16_swap / v_permlane32_swap) so that ONE LANE holds
+ *            all seven sums of ONE day -- lane l: pass l >> 5, day l & 31 of the block -- and that lane runs the
+ *            day's scalar arithmetic where the numbers are.  Today's n_i reaches the later days' sums with one
+ *            v_fmac_f64_dpp row_newbcast per compartment (the multiplicand is the lane's table row of lag
+ *            (its day - today), a row of zeros once its day is over), so a day costs ~50 instructions for both
+ *            passes together instead of fetching seven sums into every lane.
  *
  * Everything a chain touches during a launch -- parameter vector, proposal, both histories, weighted deaths --
  * lives in the wave's slice of LDS; HBM is read at the start of a launch and written at its end (and by
@@ -36,20 +39,29 @@
 #define MCMC_WV_HLO 16        /* zero history entries kept below day 0 (phase A reads down to s - 15) */
 #define MCMC_WV_HHI 20        /* ... and above the simulated horizon (phase A reads up to j0 + 18, as zeros; j0 <= horizon) */
 
+typedef double double2_t __attribute__((ext_vector_type(2)));
+#define MCMC_WV_KROW 12       /* doubles per row of the phase-B lag table: the 8 of Rpos, the 4 of Rneg */
+#define MCMC_WV_KROWS (2 * MCMC_WV_B - 1)      /* lags -(B-1) .. B-1 */
+
 __host__ __device__ inline size_t wave_slice_doubles(const DevModel& M, int dim) {
     const size_t histLen = (size_t)M.simDays + MCMC_WV_HLO + MCMC_WV_HHI;
-    return 4 * histLen + 2 * (size_t)M.nData + 2 * (size_t)dim + MCMC_WAVE;
+    return 4 * histLen + 2 * (size_t)M.nData + 2 * (size_t)dim;
 }
-/* LDS of a workgroup of `waves` chains: the shared image of tables and series + one slice per wave */
+/* doubles of the part of LDS the waves of a workgroup share: the image of tables and series (stage_lds), then, 16-byte
+ * aligned, the phase-B lag table (stage_wave_lags) */
+__host__ __device__ inline size_t wave_shared_doubles(const DevModel& M) {
+    const size_t img = ((lds_bytes(M, false, MCMC_WV_T) + 15) / 16) * 2;
+    return img + (size_t)MCMC_WV_KROWS * MCMC_WV_KROW;
+}
+/* LDS of a workgroup of `waves` chains: the shared part + one slice per wave */
 __host__ __device__ inline size_t wave_lds_bytes(const DevModel& M, int dim, int waves) {
-    return ((lds_bytes(M, false, MCMC_WV_T) + 7) / 8 + (size_t)waves * wave_slice_doubles(M, dim)) * sizeof(double);
+    return (wave_shared_doubles(M) + (size_t)waves * wave_slice_doubles(M, dim)) * sizeof(double);
 }
 
 /* the wave's slice */
 struct WaveSlice {
     double* hn[2];     /* [histLen] infections per day of either pass, day k at hn[p][k + MCMC_WV_HLO] */
     double* he[2];     /* [histLen] extra deaths per day                            */
-    double* dummy;     /* [64] one slot per lane for the stores of the branch-free day loop that must not happen */
     double* d1;        /* [nData] weighted deaths of the first pass (shift 1)       */
     double* d0;        /* [nData] ... of the second                                 */
     double* terms;     /* [max(nData, nB)] per-day / per-node terms awaiting their ordered sum: the room of he[0], which is
@@ -70,43 +82,86 @@ __device__ __forceinline__ double readlane_f64(double v, int srcLane) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double both_f64(double lo, double hi, bool hiHalf) { return hiHalf ? hi : lo; }
 __device__ __forceinline__ double uniform_f64(double v) {
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
     const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
 
-/* What phase B multiplies with never changes: the lane that holds (compartment row q / 4 + q, day n) of a block
- * needs, on the block's day t, the table rows of lag n - t -- or nothing if its day is already over.  Loaded once
- * per launch; a zero stands for "day over" (the multiply-add then leaves the finished sum, which nobody reads
- * again, unchanged). */
-struct WaveRows {
-    double p0[MCMC_WV_T];     /* R_q[n - t]      (MI, HI, INC, MILD) */
-    double p1[MCMC_WV_T];     /* R_{4+q}[n - t]  (SER, REC, DEAD, 0) */
-    double ng[MCMC_WV_T];     /* the FromSerious curve of SER / REC / DEAD at lag n - t, else 0 */
-    double f0[MCMC_WV_T];     /* the same three at lag 16 + n - t: what a day t < 16 pushes into the block's second half */
-    double f1[MCMC_WV_T];
-    double fg[MCMC_WV_T];
-    double ng0[3];            /* the three FromSerious curves at lag 0 (today's own sums), the same in every lane */
-};
-__device__ __forceinline__ void load_wave_rows(const LdsView& lds, unsigned lane, WaveRows& R) {
-    const int q = (int)(lane >> 4), n = (int)(lane & 15);
-#pragma unroll
-    for (int t = 0; t < MCMC_WV_T; ++t) {
-        const int d = n - t;
-        const int dd = max(d, 0);
-        const double a = lds.Rpos[dd * 8 + q], b = lds.Rpos[dd * 8 + 4 + q], g = lds.Rneg[dd * 4 + min(q, 2)];
-        R.p0[t] = d >= 0 ? a : 0.0;
-        R.p1[t] = d >= 0 ? b : 0.0;
-        R.ng[t] = (d >= 0 && q < 3) ? g : 0.0;
-        const int df = MCMC_WV_T + n - t;                               /* 1 .. 31 */
-        R.f0[t] = lds.Rpos[df * 8 + q];
-        R.f1[t] = lds.Rpos[df * 8 + 4 + q];
-        R.fg[t] = q < 3 ? lds.Rneg[df * 4 + q] : 0.0;
-    }
-    R.ng0[0] = lds.Rneg[0]; R.ng0[1] = lds.Rneg[1]; R.ng0[2] = lds.Rneg[2];
+/* The two row exchanges of gfx950, as measured by tools/ubench/permlane_swap.hip (rows = groups of 16 lanes):
+ *   v_permlane16_swap a, b:  a' = (a.row0, b.row0, a.row2, b.row2)   b' = (a.row1, b.row1, a.row3, b.row3)
+ *   v_permlane32_swap a, b:  a' = (a.row0, a.row1, b.row0, b.row1)   b' = (a.row2, a.row3, b.row2, b.row3)   */
+__device__ __forceinline__ void swap16_f64(double& a, double& b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
 }
+__device__ __forceinline__ void swap32_f64(double& a, double& b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+/* G[i] holds, in row r of the wave, element (r, i) of a 4 x 4 matrix of rows; afterwards G[i] holds element (i, r) */
+__device__ __forceinline__ void wave_transpose4(double (&G)[4]) {
+    swap16_f64(G[0], G[1]);
+    swap16_f64(G[2], G[3]);
+    swap32_f64(G[0], G[2]);
+    swap32_f64(G[1], G[3]);
+}
+/* rows 0, 1 <- row 0 and rows 2, 3 <- row 2 of v (EVEN), or rows 0, 1 <- row 1 and rows 2, 3 <- row 3 (odd) */
+template <bool EVEN>
+__device__ __forceinline__ double row_pair_bcast(double v) {
+    double a = v, b = v;
+    swap16_f64(a, b);
+    return EVEN ? a : b;
+}
+
+/* The phase-B lag table, shared by the workgroup: row (lag + B - 1) holds, for the lags -(B-1) .. B-1 between a
+ * destination day of a block and the block's current day, what a destination multiplies today's numbers with --
+ * [0..7] the row of Rpos (today's new infections; zeros for lag < 0: the destination's day is over) and
+ * [8..11] the row of Rneg (today's capacity correction; zeros for lag <= 0: today's own sums take theirs from
+ * registers, covid.h:413-429).  Zeros make the multiply-add leave a finished sum as it is, which phase B relies on. */
+__device__ inline const double* stage_wave_lags(const LdsView& lds, double* lds_raw, const DevModel& M, int ldsRows) {
+    double* kt = lds_raw + (wave_shared_doubles(M) - (size_t)MCMC_WV_KROWS * MCMC_WV_KROW);
+    for (int i = threadIdx.x; i < MCMC_WV_KROWS * MCMC_WV_KROW; i += blockDim.x) {
+        const int lag = i / MCMC_WV_KROW - (MCMC_WV_B - 1), c = i % MCMC_WV_KROW;
+        double v = 0.0;
+        if (lag < ldsRows) {
+            if (c < 8 && lag >= 0) v = lds.Rpos[lag * 8 + c];
+            if (c >= 8 && lag >= 1) v = lds.Rneg[lag * 4 + (c - 8)];
+        }
+        kt[i] = v;
+    }
+    __syncthreads();
+    return kt;
+}
+
+/* S[c] += (nb of lane L of the lane's own row) * k[c] for the seven compartments: v_fmac_f64 with a DPP source is the
+ * same fused operation as v_fmac_f64.  The s_nop covers the two wait states a DPP source needs after a VALU
+ * write, which the compiler cannot see into the asm to provide.  All 64 lanes are active wherever this is used. */
+#define MCMC_WV_FMAC(D, K, L) "v_fmac_f64_dpp " D ", %[nb], " K " row_newbcast:" #L " row_mask:0xf bank_mask:0xf\n\t"
+#define MCMC_WV_PUSH_CASE(L)                                                                                            \
+    case L:                                                                                                             \
+        asm("s_nop 1\n\t" MCMC_WV_FMAC("%0", "%[k0]", L) MCMC_WV_FMAC("%1", "%[k1]", L) MCMC_WV_FMAC("%2", "%[k2]", L)  \
+            MCMC_WV_FMAC("%3", "%[k3]", L) MCMC_WV_FMAC("%4", "%[k4]", L) MCMC_WV_FMAC("%5", "%[k5]", L)                \
+            MCMC_WV_FMAC("%6", "%[k6]", L)                                                                              \
+            : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(S[4]), "+v"(S[5]), "+v"(S[6])                        \
+            : [nb] "v"(nb), [k0] "v"(k0), [k1] "v"(k1), [k2] "v"(k2), [k3] "v"(k3), [k4] "v"(k4), [k5] "v"(k5),          \
+              [k6] "v"(k6));                                                                                            \
+        break;
+__device__ __forceinline__ void wave_push7(double (&S)[7], int srcLane, double nb, double k0, double k1, double k2,
+                                           double k3, double k4, double k5, double k6) {
+    switch (srcLane) {                     /* a constant wherever this is called: the day loop is unrolled */
+        MCMC_WV_PUSH_CASE(0) MCMC_WV_PUSH_CASE(1) MCMC_WV_PUSH_CASE(2) MCMC_WV_PUSH_CASE(3)
+        MCMC_WV_PUSH_CASE(4) MCMC_WV_PUSH_CASE(5) MCMC_WV_PUSH_CASE(6) MCMC_WV_PUSH_CASE(7)
+        MCMC_WV_PUSH_CASE(8) MCMC_WV_PUSH_CASE(9) MCMC_WV_PUSH_CASE(10) MCMC_WV_PUSH_CASE(11)
+        MCMC_WV_PUSH_CASE(12) MCMC_WV_PUSH_CASE(13) MCMC_WV_PUSH_CASE(14)
+        default: MCMC_WV_PUSH_CASE(15)
+    }
+}
+#undef MCMC_WV_PUSH_CASE
 
 /*
  * DiseaseSpread::eval (covid.h:325-496) of the parameter vector W.xp for the chain of this WAVE.  Every lane
@@ -117,18 +172,17 @@ __device__ __forceinline__ void load_wave_rows(const LdsView& lds, unsigned lane
  * p = 0 is shift 1 (the first in the reference's order), p = 1 is shift 0.  Two independent matrix-instruction
  * chains keep the matrix pipe at its throughput instead of one chain's latency (116 against 62 ns per
  * instruction, tools/ubench/mfma_f64.hip), and the two sequential day chains fill each other's latency gaps.
- * The day loop is branch-free for that reason (stores go to a per-lane dummy slot when they must not happen).
+ * The day loop is straight-line for that reason (its one branch, a capacity correction today, is wave-uniform).
  */
 __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsView& lds, const WaveSlice& W,
                                                   const LaneScalars& lp, unsigned lane, WorkCount& work, int ldsRows,
-                                                  const WaveRows& BR, PhaseClock& pc) {
+                                                  const double* lagTab, PhaseClock& pc) {
     const int md = M.md;
     const int horizon = M.simDays;
     const int q = (int)(lane >> 4), n = (int)(lane & 15);     /* MFMA result: rows q, q+4, q+8, q+12 of column n */
     const int kk = q, m = n;                                   /* MFMA operands: A[m][kk], B[kk][n]               */
     const int rowsM1 = ldsRows - 1;
     const double* xdisc = W.xp + M.nB;
-    double* const dummy = W.dummy + lane;                       /* where a store that must not happen goes */
 
     int start = (int)((double)md - lp.delay);                       /* covid.h:331 */
     const double frac = (double)md - lp.delay - (double)start;      /* covid.h:332 */
@@ -136,10 +190,11 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
     start = __builtin_amdgcn_readfirstlane(start);
     count_work(M, start, work);
 
-    const bool hiHalf = lane >= 32;                              /* phase B: which pass's day arithmetic the lane carries */
+    const bool hiHalf = lane >= 32;                              /* phase B: the pass whose days the lane carries ... */
+    const int dayInBlk = (int)(lane & 31);                       /* ... and which day of a block */
     int sP[2];
-    double wP[2], ncurS[2];                                       /* n of the current day of either pass, the same in every lane */
-    double ncurB = 1.0;                                           /* ... and as the lanes of the day chain hold it */
+    double wP[2];
+    double nb = 1.0;                                              /* what today's push broadcasts; patient zero on day s, covid.h:339 */
     double* hnP[2] = {W.hn[0], W.hn[1]};
     double* heP[2] = {W.he[0], W.he[1]};
     int keLo[2], keHi[2];                                           /* source days with a capacity correction */
@@ -148,13 +203,14 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
         const int shift = 1 - p;
         wP[p] = (double)(1 - shift) * (1.0 - frac) + (double)shift * frac;      /* covid.h:333 */
         sP[p] = min(start + shift, horizon);
-        ncurS[p] = 1.0;                                             /* patient zero on day s, covid.h:339 */
         keLo[p] = 0x7fffffff; keHi[p] = -1;
     }
     double* const hnDst = (hiHalf ? W.hn[1] : W.hn[0]) + MCMC_WV_HLO;
     double* const heDst = (hiHalf ? W.he[1] : W.he[0]) + MCMC_WV_HLO;
     double* const dsDst = hiHalf ? W.d0 : W.d1;
     const double wBoth = hiHalf ? wP[1] : wP[0];
+    const double* const kLane = lagTab + dayInBlk * MCMC_WV_KROW;  /* the lane's row of lag (its day - day t of the block) is kLane + (B-1-t) rows */
+    const double ng0S = lds.Rneg[0], ng0R = lds.Rneg[1], ng0D = lds.Rneg[2];      /* FromSerious at lag 0: today's own sums */
     for (int k = (int)lane; k < W.histLen; k += MCMC_WAVE) {
         W.hn[0][k] = 0.0; W.he[0][k] = 0.0; W.hn[1][k] = 0.0; W.he[1][k] = 0.0;
     }
@@ -233,95 +289,113 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
             }
         }
         pc.stamp(PH_CHUNKS);
-        /* ---------- phase B: the block's days in order, both passes day for day.  cc[p][0] = (MI, HI, INC, MILD)[q] and
-         * cc[p][1] = (SER, REC, DEAD, -)[q] of day n; cc[p][2], cc[p][3] the same of day 16 + n.  The day's scalar
-         * arithmetic is the same for both passes on different numbers: lanes 0..31 carry pass 0's, lanes 32..63
-         * pass 1's, so ONE sequential chain of operations serves both. */
-        double cc[2][4] = {{c0[0], c0[1], c0[2], c0[3]}, {c1[0], c1[1], c1[2], c1[3]}};
-        double keLoB = hiHalf ? (double)keLo[1] : (double)keLo[0], keHiB = hiHalf ? (double)keHi[1] : (double)keHi[0];
-        const int j0B = hiHalf ? j0P[1] : j0P[0];
+        /* ---------- phase B: the block's days in order, both passes day for day.  The tiles hold (MI, HI, INC, MILD)[q]
+         * and (SER, REC, DEAD, -)[q] of day n and of day 16 + n in the lanes (q, n); two 4 x 4 transpositions of rows
+         * bring all seven sums of day (l & 31) of pass (l >> 5) into lane l.  From then on lane l's sums only
+         * change while its day is not over (the lag table holds zeros for the days that are), and whatever it
+         * computes from them on the days after its own it computes again, the same: so every lane runs the day
+         * arithmetic on every day, the lane whose day it is feeds the next push, and the results are stored once,
+         * from all lanes, after the block. */
+        double Sx[7];
+        {
+            double G[4] = {c0[0], c0[2], c1[0], c1[2]}, Hh[4] = {c0[1], c0[3], c1[1], c1[3]};
+            if (blk > 0) {                                                       /* the first block's are zeros */
+                wave_transpose4(G);
+                wave_transpose4(Hh);
+            }
+            Sx[0] = G[0]; Sx[1] = G[1]; Sx[2] = G[2]; Sx[3] = G[3];
+            Sx[4] = Hh[0]; Sx[5] = Hh[1]; Sx[6] = Hh[2];
+        }
+        const int iB = (hiHalf ? j0P[1] : j0P[0]) + dayInBlk;                   /* the lane's day */
+        const bool live = iB < horizon;                                          /* days beyond compute garbage nobody reads */
+        /* the block's first day enters the history only now: phase A takes a source day k >= j0 for zero, which
+         * keeps the in-block sources (phase B's) out of it without a mask.  nb of lane 31 / 63 is that day's n */
+        if (dayInBlk == MCMC_WV_B - 1 && iB - (MCMC_WV_B - 1) < horizon) hnDst[iB - (MCMC_WV_B - 1)] = nb;
+        /* what the day needs besides the sums: capacity and pcf * smoothbehavior (covid.h:432-454) */
+        double capL, tbL;
+        {
+            const int iC = min(iB, M.simPad - 1);
+            capL = lds.capacity[iC];
+            const int sg = lds.seg[iC];
+            const double pcf = sg >= 0 ? xdisc[max(sg, 0)] : 1.0;
+            double smoothbehavior = 1.0;
+            if (iC >= md) smoothbehavior = pcf * W.xp[min(max(iC - md, 0), M.nB - 1)];
+            tbL = pcf * smoothbehavior;
+        }
+        double nn = 0.0, eL = 0.0, deadL = 0.0;
+        bool hasE = false;
+        const unsigned long long liveMask = __builtin_amdgcn_ballot_w64(live);
+        /* the lane's table row of a day is requested a day ahead: LDS latency stays off the sequential chain */
+        struct LagRow { double2_t k01, k23, k45; double k6; };
+        auto lag_row = [&](int t) {
+            const double* kr = kLane + (MCMC_WV_B - 1 - t) * MCMC_WV_KROW;
+            LagRow r;
+            r.k01 = *(const double2_t*)(kr); r.k23 = *(const double2_t*)(kr + 2); r.k45 = *(const double2_t*)(kr + 4);
+            r.k6 = kr[6];
+            return r;
+        };
+        LagRow kc = lag_row(0);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            if (half == 1 && !(j0P[1] + MCMC_WV_T < horizon)) break;        /* wave-uniform: nothing of the second half is simulated */
-            /* what the days need besides the sums, the lane's own pass: capacity and pcf * smoothbehavior (covid.h:432-454) */
-            double capB[MCMC_WV_T], tbB[MCMC_WV_T];
+            if (half == 1 && !(j0P[1] + MCMC_WV_T < horizon)) break;            /* wave-uniform: nothing of the second half is simulated */
 #pragma unroll
             for (int u = 0; u < MCMC_WV_T; ++u) {
-                const int iB = min(j0B + half * MCMC_WV_T + u, M.simPad - 1);
-                capB[u] = lds.capacity[iB];
-                const int sg = lds.seg[iB];
-                const double pcf = sg >= 0 ? xdisc[max(sg, 0)] : 1.0;
-                double smoothbehavior = 1.0;
-                if (iB >= md) smoothbehavior = pcf * W.xp[min(max(iB - md, 0), M.nB - 1)];
-                tbB[u] = pcf * smoothbehavior;
-            }
-#pragma unroll
-            for (int u = 0; u < MCMC_WV_T; ++u) {
-                const int iB = j0B + half * MCMC_WV_T + u;                          /* the lane's pass's day */
-                const bool writer = (lane & 31) == 0 && iB < horizon;               /* days beyond compute garbage nobody reads */
-                *(writer ? hnDst + iB : dummy) = ncurB;
+                const int t = half * MCMC_WV_T + u;
+                const double* kr = kLane + (MCMC_WV_B - 1 - t) * MCMC_WV_KROW;
+                const LagRow kn = lag_row(min(t + 1, MCMC_WV_B - 1));
                 /* today's new infections into today and the rest of the block (covid.h:403-410) */
-                double va[2], vb[2];                                                /* the half that holds today */
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    if (half == 0) {
-                        cc[p][0] = __builtin_fma(ncurS[p], BR.p0[u], cc[p][0]);
-                        cc[p][1] = __builtin_fma(ncurS[p], BR.p1[u], cc[p][1]);
-                        cc[p][2] = __builtin_fma(ncurS[p], BR.f0[u], cc[p][2]);
-                        cc[p][3] = __builtin_fma(ncurS[p], BR.f1[u], cc[p][3]);
-                        va[p] = cc[p][0]; vb[p] = cc[p][1];
-                    } else {
-                        cc[p][2] = __builtin_fma(ncurS[p], BR.p0[u], cc[p][2]);
-                        cc[p][3] = __builtin_fma(ncurS[p], BR.p1[u], cc[p][3]);
-                        va[p] = cc[p][2]; vb[p] = cc[p][3];
-                    }
-                }
-                /* both lanes' values are fetched, then selected: a select AROUND the (convergent) lane reads becomes branches */
-#define MCMC_BOTH(v, srcLane) both_f64(readlane_f64((v)[0], srcLane), readlane_f64((v)[1], srcLane), hiHalf)
-                const double vMI = MCMC_BOTH(va, u), vHI = MCMC_BOTH(va, 16 + u), vINC = MCMC_BOTH(va, 32 + u), vMILD = MCMC_BOTH(va, 48 + u);
-                double vSER = MCMC_BOTH(vb, u), vREC = MCMC_BOTH(vb, 16 + u), vDEAD = MCMC_BOTH(vb, 32 + u);
-#undef MCMC_BOTH
+                wave_push7(Sx, (u + MCMC_WV_T - 1) & (MCMC_WV_T - 1), nb, kc.k01[0], kc.k01[1], kc.k23[0], kc.k23[1],
+                           kc.k45[0], kc.k45[1], kc.k6);
+                kc = kn;
+                const double vMI = Sx[0], vHI = Sx[1], vINC = Sx[2], vMILD = Sx[3];
+                double vSER = Sx[4], vREC = Sx[5], vDEAD = Sx[6];
                 /* hospital capacity (covid.h:413-429).  Straight-line: without a correction e = +0, and adding
                  * +0 or the product -0 * x changes no sum (none of them is ever -0) */
-                const double overCapacity = vSER * M.probICU - capB[u];
+                const double overCapacity = vSER * M.probICU - capL;
                 const double extraDeaths = M.probLethal * overCapacity;
-                const bool hasE = extraDeaths > 0;
-                const double e = hasE ? extraDeaths : 0.0, ne = -e;
-                *(writer ? heDst + iB : dummy) = e;
-                keLoB = (hasE && iB < horizon) ? fmin(keLoB, (double)iB) : keLoB;
-                keHiB = (hasE && iB < horizon) ? fmax(keHiB, (double)iB) : keHiB;
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {                                       /* the later days' sums: + e (deaths), then the projections */
-                    const double eS = readlane_f64(e, 32 * p);
-                    const double eDead = (q == 2) ? eS : 0.0;
-                    if (half == 0) {
-                        cc[p][1] = cc[p][1] + eDead;
-                        cc[p][1] = __builtin_fma(-eS, BR.ng[u], cc[p][1]);
-                        cc[p][3] = cc[p][3] + eDead;
-                        cc[p][3] = __builtin_fma(-eS, BR.fg[u], cc[p][3]);
-                    } else {
-                        cc[p][3] = cc[p][3] + eDead;
-                        cc[p][3] = __builtin_fma(-eS, BR.ng[u], cc[p][3]);
-                    }
-                }
-                vDEAD = vDEAD + e;                                                  /* today's own sums, the same operations */
-                vSER = __builtin_fma(ne, BR.ng0[0], vSER);
-                vREC = __builtin_fma(ne, BR.ng0[1], vREC);
-                vDEAD = __builtin_fma(ne, BR.ng0[2], vDEAD);
+                const unsigned long long gt = __builtin_amdgcn_fcmp(extraDeaths, 0.0, 2 /* ordered > */) & liveMask;
+                hasE = live && extraDeaths > 0;
+                eL = hasE ? extraDeaths : 0.0;
+                const double ne = -eL;
+                vDEAD = vDEAD + eL;                                                 /* today's own sums */
+                vSER = __builtin_fma(ne, ng0S, vSER);
+                vREC = __builtin_fma(ne, ng0R, vREC);
+                vDEAD = __builtin_fma(ne, ng0D, vDEAD);
+                deadL = vDEAD;
                 /* tomorrow's new infections (covid.h:461-462); asymptomatic == mild buffer */
                 const double nSus = M.pop - vINC - vMILD - vMILD - vSER - vREC - vDEAD;
-                const double nnext = tbB[u] * nSus / M.pop * (lp.betaMild * vMI + lp.betaHigh * vHI);
-                const bool stD = writer && iB >= md && iB - md < M.nData;
-                *(stD ? dsDst + (iB - md) : dummy) = wBoth * vDEAD;                 /* covid.h:475,484 */
-                ncurB = nnext;
-                ncurS[0] = readlane_f64(nnext, 0);
-                ncurS[1] = readlane_f64(nnext, 32);
+                nn = tbL * nSus / M.pop * (lp.betaMild * vMI + lp.betaHigh * vHI);
+                /* the later days' sums: + e (deaths), then the projections.  Only the lanes whose day it is decide */
+                const unsigned long long today = (1ull << t) | (1ull << (32 + t));
+                if (gt & today) {
+                    const double e0 = readlane_f64(eL, t), e1 = readlane_f64(eL, 32 + t);
+                    const double eb = hiHalf ? e1 : e0, neb = -eb;
+                    const double2_t n01 = *(const double2_t*)(kr + 8), n23 = *(const double2_t*)(kr + 10);
+                    Sx[6] = __builtin_fma(eb, n23[1], Sx[6]);                       /* the flat add: 1 within the table's lags */
+                    Sx[4] = __builtin_fma(neb, n01[0], Sx[4]);
+                    Sx[5] = __builtin_fma(neb, n01[1], Sx[5]);
+                    Sx[6] = __builtin_fma(neb, n23[0], Sx[6]);
+                }
+                /* tomorrow's push reads lane u of every row: the second half's lanes get the first half's number */
+                nb = half == 0 ? row_pair_bcast<true>(nn) : nn;
             }
         }
+        nb = row_pair_bcast<false>(nn);                                             /* day 31's, for the next block's day 0 */
+        if (dayInBlk < MCMC_WV_B - 1 && iB + 1 < horizon) hnDst[iB + 1] = nn;     /* day 31's: by the next block, see above */
+        if (live) {
+            heDst[iB] = eL;
+            if (iB >= md && iB - md < M.nData) dsDst[iB - md] = wBoth * deadL;      /* covid.h:475,484 */
+        }
+        {
+            const unsigned long long hm = __builtin_amdgcn_ballot_w64(hasE);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            keLo[p] = (int)readlane_f64(keLoB, 32 * p);
-            keHi[p] = (int)readlane_f64(keHiB, 32 * p);
+            for (int p = 0; p < 2; ++p) {
+                const unsigned m32 = (unsigned)(hm >> (32 * p));
+                if (m32) {
+                    keLo[p] = min(keLo[p], j0P[p] + (int)__builtin_ctz(m32));
+                    keHi[p] = max(keHi[p], j0P[p] + 31 - (int)__builtin_clz(m32));
+                }
+            }
         }
         pc.stamp(PH_DAYS);
         wave_sync();
@@ -470,6 +544,7 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, 
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     const LdsView lds = stage_lds(M, lds_raw, false, MCMC_WV_T);
     const int ldsRows = lds_rows(M, false, MCMC_WV_T);
+    const double* lagTab = stage_wave_lags(lds, lds_raw, M, ldsRows);
     const unsigned lane = threadIdx.x & (MCMC_WAVE - 1);
     const int waveInBlock = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / MCMC_WAVE));
     const int wavesPerBlock = (int)(blockDim.x / MCMC_WAVE);       /* 4, or fewer where the series leaves LDS for fewer slices */
@@ -482,12 +557,11 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, 
     WaveSlice W;
     W.histLen = M.simDays + MCMC_WV_HLO + MCMC_WV_HHI;
     {
-        double* p = lds_raw + (lds_bytes(M, false, MCMC_WV_T) + 7) / 8 + (size_t)waveInBlock * wave_slice_doubles(M, dim);
+        double* p = lds_raw + wave_shared_doubles(M) + (size_t)waveInBlock * wave_slice_doubles(M, dim);
         W.hn[0] = p; p += W.histLen;
         W.hn[1] = p; p += W.histLen;
         W.he[0] = p; p += W.histLen;
         W.he[1] = p; p += W.histLen;
-        W.dummy = p; p += MCMC_WAVE;
         W.d1 = p; p += M.nData;
         W.d0 = p; p += M.nData;
         W.terms = W.he[0];                 /* histLen = simDays + 36 > nData, nB */
@@ -513,9 +587,6 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, 
     work.exec = pairs_g[MCMC_WAVE];
     const double rungBeta = S.chainBeta ? S.chainBeta[flat] : 1.0;
     int slot = slot0;
-    WaveRows BR;
-    load_wave_rows(lds, lane, BR);
-    wave_sync();
     PhaseClock pc;
     pc.start();
 
@@ -552,7 +623,7 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, 
         pc.stamp(PH_RECORD);
         const bool behChanged = propose_wave(M, rnd, W, lane, stepsize, lp, llpNew);
         pc.stamp(PH_PROPOSE);
-        const double llm = eval_model_wave(M, lds, W, lp, lane, work, ldsRows, BR, pc);
+        const double llm = eval_model_wave(M, lds, W, lp, lane, work, ldsRows, lagTab, pc);
         double llp = 0.0;
         double delta = 0;                                           /* mcmc.h:604-606 */
         delta += -llModel + llm;
