@@ -163,6 +163,33 @@ __device__ __forceinline__ void wave_push7(double (&S)[7], int srcLane, double n
 }
 #undef MCMC_WV_PUSH_CASE
 
+/* sum = (((sum + sgn t[0]) + sgn t[1]) + ...) + sgn t[count-1], sgn = +1 or -1: the reference's running sums (covid.h:488-492,
+ * mcmc.h:197-214) are ordered, so this is one dependent chain -- of v_fmac_f64_dpp, which IS the add (x * 1 is exact),
+ * with the addend of step i broadcast from lane i & 15 of each row: every row reads the same 16 terms from LDS, so
+ * every lane runs the same chain and ends with the same sum.  Eight groups of 16 are requested before their 128 adds,
+ * which keeps LDS latency off the chain.  t[count .. count + 15] must be zeros (a ragged last group adds them). */
+__device__ __forceinline__ void ordered_add16(double& sum, double t, double sgn) {
+#define MCMC_WV_ADD(L) "v_fmac_f64_dpp %0, %[t], %[s] row_newbcast:" #L " row_mask:0xf bank_mask:0xf\n\t"
+    asm("s_nop 1\n\t" MCMC_WV_ADD(0) MCMC_WV_ADD(1) MCMC_WV_ADD(2) MCMC_WV_ADD(3) MCMC_WV_ADD(4) MCMC_WV_ADD(5) MCMC_WV_ADD(6)
+        MCMC_WV_ADD(7) MCMC_WV_ADD(8) MCMC_WV_ADD(9) MCMC_WV_ADD(10) MCMC_WV_ADD(11) MCMC_WV_ADD(12) MCMC_WV_ADD(13)
+        MCMC_WV_ADD(14) MCMC_WV_ADD(15)
+        : "+v"(sum) : [t] "v"(t), [s] "v"(sgn));
+#undef MCMC_WV_ADD
+}
+__device__ __forceinline__ double ordered_sum(double sum, const double* t, int count, unsigned lane, double sgn) {
+    const double* tp = t + (lane & 15);
+#pragma unroll 1
+    for (int base = 0; base < count; base += 128) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tp[base + 16 * j];           /* beyond count: inside the wave's slice, not added */
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (base + 16 * j < count) ordered_add16(sum, v[j], sgn);
+    }
+    return sum;
+}
+
 /*
  * DiseaseSpread::eval (covid.h:325-496) of the parameter vector W.xp for the chain of this WAVE.  Every lane
  * returns the same loglike.  Same operations on every accumulator, in the same order, as eval_model<T, true>.
@@ -412,9 +439,9 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
             const double delta = dv - lds.deaths[i];
             W.terms[i] = w * (-0.5 * delta * delta / lds.sigma2[i]);
         }
+        if (lane < 16) W.terms[M.nData + lane] = 0.0;
         wave_sync();
-#pragma unroll 8
-        for (int i = 0; i < M.nData; ++i) loglike += W.terms[i];
+        loglike = ordered_sum(loglike, W.terms, M.nData, lane, 1.0);
         wave_sync();
     }
     pc.stamp(PH_LOGLIKE);
@@ -508,10 +535,9 @@ __device__ inline bool propose_wave(const DevModel& M, Pcg32& rnd, const WaveSli
             const double dd = v + fm - 2 * f0;
             W.terms[i] = div3(dd * dd, dx, dxPow2, invDx);
         }
+        if (lane < 16) W.terms[nB + lane] = 0.0;
         wave_sync();
-        double loglike = 0;
-#pragma unroll 8
-        for (int i = 2; i < nB; ++i) loglike -= W.terms[i];
+        double loglike = ordered_sum(0.0, W.terms + 2, nB - 2, lane, -1.0);
         loglike *= M.smoothLs * M.smoothLs / M.smoothL;
         priorOut = loglike;
         wave_sync();
