@@ -34,10 +34,11 @@
  */
 #pragma once
 
-#define MCMC_WV_T 16          /* the 16 columns of the MFMA tile: days per HALF block */
-#define MCMC_WV_B 32          /* days per block: rows 0..6 of the tile hold the block's days 0..15, rows 8..14 its days 16..31 */
-#define MCMC_WV_HLO 16        /* zero history entries kept below day 0 (phase A reads down to s - 15) */
-#define MCMC_WV_HHI 20        /* ... and above the simulated horizon (phase A reads up to j0 + 18, as zeros; j0 <= horizon) */
+#define MCMC_WV_T 16          /* lanes of a DPP row: days per HALF block, lags per group of phase A */
+#define MCMC_WV_B 32          /* days per block: lane l carries day l & 31 of the block for pass l >> 5 */
+#define MCMC_WV_HLO 32        /* zero history entries kept below day 0 (phase A reads down to s - 32) */
+#define MCMC_WV_HHI 32        /* ... and above the simulated horizon (phase A reads up to j0 + 30, as zeros; j0 <= horizon) */
+#define MCMC_WV_NTAB 10       /* curves of the transposed table: MI HI INC MILD SER REC DEAD, -SFS -RFS -DFS */
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 #define MCMC_WV_KROW 12       /* doubles per row of the phase-B lag table: the 8 of Rpos, the 4 of Rneg */
@@ -47,11 +48,20 @@ __host__ __device__ inline size_t wave_slice_doubles(const DevModel& M, int dim)
     const size_t histLen = (size_t)M.simDays + MCMC_WV_HLO + MCMC_WV_HHI;
     return 4 * histLen + 2 * (size_t)M.nData + 2 * (size_t)dim;
 }
-/* doubles of the part of LDS the waves of a workgroup share: the image of tables and series (stage_lds), then, 16-byte
- * aligned, the phase-B lag table (stage_wave_lags) */
+/* rows (lags) of the transposed table in LDS: phase A reads lags up to (days simulated so far) + 32; every lag from
+ * nLagRows on is a zero (the d < nDays cut-off of project(), covid.h:378) and reads the one zero row kept for them */
+__host__ __device__ inline int wave_tab_rows(const DevModel& M) {
+    const int a = M.simDays + MCMC_WV_B + 1, b = M.nLagRows + 1;
+    return a < b ? a : b;
+}
+/* doubles of the part of LDS the waves of a workgroup share (stage_wave_image): the table, curve-major; capacity,
+ * deaths, sigma^2; the segment index (ints); then, 16-byte aligned, the phase-B lag table */
+__host__ __device__ inline size_t wave_image_doubles(const DevModel& M) {
+    const size_t d = (size_t)MCMC_WV_NTAB * wave_tab_rows(M) + (size_t)M.simPad + 2 * (size_t)M.nData + ((size_t)M.simPad + 1) / 2;
+    return (d + 1) / 2 * 2;
+}
 __host__ __device__ inline size_t wave_shared_doubles(const DevModel& M) {
-    const size_t img = ((lds_bytes(M, false, MCMC_WV_T) + 15) / 16) * 2;
-    return img + (size_t)MCMC_WV_KROWS * MCMC_WV_KROW;
+    return wave_image_doubles(M) + (size_t)MCMC_WV_KROWS * MCMC_WV_KROW;
 }
 /* LDS of a workgroup of `waves` chains: the shared part + one slice per wave */
 __host__ __device__ inline size_t wave_lds_bytes(const DevModel& M, int dim, int waves) {
@@ -88,27 +98,13 @@ __device__ __forceinline__ double uniform_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 
-/* The two row exchanges of gfx950, as measured by tools/ubench/permlane_swap.hip (rows = groups of 16 lanes):
- *   v_permlane16_swap a, b:  a' = (a.row0, b.row0, a.row2, b.row2)   b' = (a.row1, b.row1, a.row3, b.row3)
- *   v_permlane32_swap a, b:  a' = (a.row0, a.row1, b.row0, b.row1)   b' = (a.row2, a.row3, b.row2, b.row3)   */
+/* The row exchange of gfx950, as measured by tools/ubench/permlane_swap.hip (rows = groups of 16 lanes):
+ *   v_permlane16_swap a, b:  a' = (a.row0, b.row0, a.row2, b.row2)   b' = (a.row1, b.row1, a.row3, b.row3)   */
 __device__ __forceinline__ void swap16_f64(double& a, double& b) {
     const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
     const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
     a = __hiloint2double((int)hi[0], (int)lo[0]);
     b = __hiloint2double((int)hi[1], (int)lo[1]);
-}
-__device__ __forceinline__ void swap32_f64(double& a, double& b) {
-    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    a = __hiloint2double((int)hi[0], (int)lo[0]);
-    b = __hiloint2double((int)hi[1], (int)lo[1]);
-}
-/* G[i] holds, in row r of the wave, element (r, i) of a 4 x 4 matrix of rows; afterwards G[i] holds element (i, r) */
-__device__ __forceinline__ void wave_transpose4(double (&G)[4]) {
-    swap16_f64(G[0], G[1]);
-    swap16_f64(G[2], G[3]);
-    swap32_f64(G[0], G[2]);
-    swap32_f64(G[1], G[3]);
 }
 /* rows 0, 1 <- row 0 and rows 2, 3 <- row 2 of v (EVEN), or rows 0, 1 <- row 1 and rows 2, 3 <- row 3 (odd) */
 template <bool EVEN>
@@ -118,24 +114,102 @@ __device__ __forceinline__ double row_pair_bcast(double v) {
     return EVEN ? a : b;
 }
 
-/* The phase-B lag table, shared by the workgroup: row (lag + B - 1) holds, for the lags -(B-1) .. B-1 between a
- * destination day of a block and the block's current day, what a destination multiplies today's numbers with --
- * [0..7] the row of Rpos (today's new infections; zeros for lag < 0: the destination's day is over) and
+/* The workgroup's shared image.  (1) The response table CURVE-major, rt[c][lag]: phase A gives lane n of every row
+ * the 16 lags of a group (one conflict-free read per curve) and broadcasts them with DPP.  The three FromSerious
+ * curves are stored negated: fma(e, -g, s) is fma(-e, g, s), bit for bit.  (2) The per-day constants and the
+ * observed series, as stage_lds.  (3) The phase-B lag table: row (lag + B - 1) holds, for the lags -(B-1) .. B-1
+ * between a destination day of a block and the block's current day, what a destination multiplies today's numbers
+ * with -- [0..7] the row of Rpos (today's new infections; zeros for lag < 0: the destination's day is over) and
  * [8..11] the row of Rneg (today's capacity correction; zeros for lag <= 0: today's own sums take theirs from
  * registers, covid.h:413-429).  Zeros make the multiply-add leave a finished sum as it is, which phase B relies on. */
-__device__ inline const double* stage_wave_lags(const LdsView& lds, double* lds_raw, const DevModel& M, int ldsRows) {
-    double* kt = lds_raw + (wave_shared_doubles(M) - (size_t)MCMC_WV_KROWS * MCMC_WV_KROW);
+struct WaveImage {
+    LdsView lds;              /* capacity, deaths, sigma2, seg (no row-major tables) */
+    const double* rt;         /* [MCMC_WV_NTAB][rows] */
+    const double* lagTab;     /* [MCMC_WV_KROWS][MCMC_WV_KROW] */
+    int rows;
+};
+__device__ inline WaveImage stage_wave_image(const DevModel& M, double* lds_raw) {
+    const int rows = wave_tab_rows(M);
+    double* rt = lds_raw;
+    double* cap = rt + (size_t)MCMC_WV_NTAB * rows;
+    double* dea = cap + M.simPad;
+    double* sg2 = dea + M.nData;
+    int* seg = (int*)(sg2 + M.nData);
+    double* kt = lds_raw + wave_image_doubles(M);
+    for (int i = threadIdx.x; i < MCMC_WV_NTAB * rows; i += blockDim.x) {
+        const int c = i / rows, L = i % rows;
+        double v = 0.0;
+        if (L < M.nLagRows) v = c < 7 ? M.Rpos[(size_t)L * 8 + c] : -M.Rneg[(size_t)L * 4 + (c - 7)];
+        rt[i] = v;
+    }
+    for (int i = threadIdx.x; i < M.simPad; i += blockDim.x) {
+        cap[i] = M.capacity[i];
+        seg[i] = M.seg[i];
+    }
+    for (int i = threadIdx.x; i < M.nData; i += blockDim.x) {
+        dea[i] = M.deaths[i];
+        sg2[i] = M.sigma2[i];
+    }
     for (int i = threadIdx.x; i < MCMC_WV_KROWS * MCMC_WV_KROW; i += blockDim.x) {
         const int lag = i / MCMC_WV_KROW - (MCMC_WV_B - 1), c = i % MCMC_WV_KROW;
         double v = 0.0;
-        if (lag < ldsRows) {
-            if (c < 8 && lag >= 0) v = lds.Rpos[lag * 8 + c];
-            if (c >= 8 && lag >= 1) v = lds.Rneg[lag * 4 + (c - 8)];
+        if (lag < M.nLagRows) {
+            if (c < 8 && lag >= 0) v = M.Rpos[(size_t)lag * 8 + c];
+            if (c >= 8 && lag >= 1) v = M.Rneg[(size_t)lag * 4 + (c - 8)];
         }
         kt[i] = v;
     }
     __syncthreads();
-    return kt;
+    WaveImage I;
+    I.lds.Rpos = nullptr; I.lds.Rneg = nullptr; I.lds.capacity = cap; I.lds.deaths = dea; I.lds.sigma2 = sg2; I.lds.seg = seg;
+    I.lds.tabF = nullptr; I.lds.tabN = nullptr; I.lds.rowsB = nullptr; I.lds.rowsNB = nullptr; I.lds.tr = nullptr;
+    I.rt = rt; I.lagTab = kt; I.rows = rows;
+    return I;
+}
+
+/* Phase A, 16 lags of all 32 days x 2 passes: S[c] += (table of lane j of the lane's own row) * h[j], j = 0..15 in
+ * order, for the seven compartments.  Lane n of every row holds the table at lag (top - n), h[j] is the lane's
+ * own source day of lag (top - j): descending lags are ascending source days, the reference's order. */
+#define MCMC_WV_F(D, T, H, L) "v_fmac_f64_dpp " D ", " T ", " H " row_newbcast:" #L " row_mask:0xf bank_mask:0xf\n\t"
+#define MCMC_WV_LAG7(H, L)                                                                                         \
+    MCMC_WV_F("%0", "%[t0]", H, L) MCMC_WV_F("%1", "%[t1]", H, L) MCMC_WV_F("%2", "%[t2]", H, L)                   \
+    MCMC_WV_F("%3", "%[t3]", H, L) MCMC_WV_F("%4", "%[t4]", H, L) MCMC_WV_F("%5", "%[t5]", H, L)                   \
+    MCMC_WV_F("%6", "%[t6]", H, L)
+#define MCMC_WV_S7 "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(S[4]), "+v"(S[5]), "+v"(S[6])
+#define MCMC_WV_T7 [t0] "v"(t[0]), [t1] "v"(t[1]), [t2] "v"(t[2]), [t3] "v"(t[3]), [t4] "v"(t[4]), [t5] "v"(t[5]), [t6] "v"(t[6])
+__device__ __forceinline__ void wave_lags8_lo(double (&S)[7], const double (&t)[7], const double* h) {
+    asm("s_nop 1\n\t" MCMC_WV_LAG7("%[h0]", 0) MCMC_WV_LAG7("%[h1]", 1) MCMC_WV_LAG7("%[h2]", 2) MCMC_WV_LAG7("%[h3]", 3)
+        MCMC_WV_LAG7("%[h4]", 4) MCMC_WV_LAG7("%[h5]", 5) MCMC_WV_LAG7("%[h6]", 6) MCMC_WV_LAG7("%[h7]", 7)
+        : MCMC_WV_S7
+        : MCMC_WV_T7, [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [h3] "v"(h[3]), [h4] "v"(h[4]), [h5] "v"(h[5]),
+          [h6] "v"(h[6]), [h7] "v"(h[7]));
+}
+__device__ __forceinline__ void wave_lags8_hi(double (&S)[7], const double (&t)[7], const double* h) {
+    asm("s_nop 1\n\t" MCMC_WV_LAG7("%[h0]", 8) MCMC_WV_LAG7("%[h1]", 9) MCMC_WV_LAG7("%[h2]", 10) MCMC_WV_LAG7("%[h3]", 11)
+        MCMC_WV_LAG7("%[h4]", 12) MCMC_WV_LAG7("%[h5]", 13) MCMC_WV_LAG7("%[h6]", 14) MCMC_WV_LAG7("%[h7]", 15)
+        : MCMC_WV_S7
+        : MCMC_WV_T7, [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [h3] "v"(h[3]), [h4] "v"(h[4]), [h5] "v"(h[5]),
+          [h6] "v"(h[6]), [h7] "v"(h[7]));
+}
+/* the same for four lags whose source days may carry capacity corrections: after the seven projections of a source
+ * day come + e (deaths; m = 1 within the table's lags, the flat add() of covid.h:387-391) and the three negative
+ * projections of e (q = the negated FromSerious curves), in the reference's order (covid.h:413-429) */
+#define MCMC_WV_LAG_E(H, E, L)                                                                                     \
+    MCMC_WV_LAG7(H, L) MCMC_WV_F("%6", "%[m]", E, L) MCMC_WV_F("%4", "%[q0]", E, L) MCMC_WV_F("%5", "%[q1]", E, L) \
+    MCMC_WV_F("%6", "%[q2]", E, L)
+#define MCMC_WV_LAGS4_E(L0, L1, L2, L3)                                                                            \
+    asm("s_nop 1\n\t" MCMC_WV_LAG_E("%[h0]", "%[e0]", L0) MCMC_WV_LAG_E("%[h1]", "%[e1]", L1)                       \
+        MCMC_WV_LAG_E("%[h2]", "%[e2]", L2) MCMC_WV_LAG_E("%[h3]", "%[e3]", L3)                                     \
+        : MCMC_WV_S7                                                                                               \
+        : MCMC_WV_T7, [m] "v"(m), [q0] "v"(q[0]), [q1] "v"(q[1]), [q2] "v"(q[2]), [h0] "v"(h[0]), [h1] "v"(h[1]),    \
+          [h2] "v"(h[2]), [h3] "v"(h[3]), [e0] "v"(e[0]), [e1] "v"(e[1]), [e2] "v"(e[2]), [e3] "v"(e[3]))
+template <int J0>
+__device__ __forceinline__ void wave_lags4_e(double (&S)[7], const double (&t)[7], const double (&q)[3], double m,
+                                             const double* h, const double* e) {
+    if constexpr (J0 == 0) MCMC_WV_LAGS4_E(0, 1, 2, 3);
+    else if constexpr (J0 == 4) MCMC_WV_LAGS4_E(4, 5, 6, 7);
+    else if constexpr (J0 == 8) MCMC_WV_LAGS4_E(8, 9, 10, 11);
+    else MCMC_WV_LAGS4_E(12, 13, 14, 15);
 }
 
 /* S[c] += (nb of lane L of the lane's own row) * k[c] for the seven compartments: v_fmac_f64 with a DPP source is the
@@ -201,14 +275,14 @@ __device__ __forceinline__ double ordered_sum(double sum, const double* t, int c
  * instruction, tools/ubench/mfma_f64.hip), and the two sequential day chains fill each other's latency gaps.
  * The day loop is straight-line for that reason (its one branch, a capacity correction today, is wave-uniform).
  */
-__device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsView& lds, const WaveSlice& W,
-                                                  const LaneScalars& lp, unsigned lane, WorkCount& work, int ldsRows,
-                                                  const double* lagTab, PhaseClock& pc) {
+__device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveImage& I, const WaveSlice& W,
+                                                  const LaneScalars& lp, unsigned lane, WorkCount& work, PhaseClock& pc) {
+    const LdsView& lds = I.lds;
+    const double* const lagTab = I.lagTab;
     const int md = M.md;
     const int horizon = M.simDays;
-    const int q = (int)(lane >> 4), n = (int)(lane & 15);     /* MFMA result: rows q, q+4, q+8, q+12 of column n */
-    const int kk = q, m = n;                                   /* MFMA operands: A[m][kk], B[kk][n]               */
-    const int rowsM1 = ldsRows - 1;
+    const int n16 = (int)(lane & 15);                          /* the lane's place in its DPP row */
+    const int rowsM1 = I.rows - 1;
     const double* xdisc = W.xp + M.nB;
 
     int start = (int)((double)md - lp.delay);                       /* covid.h:331 */
@@ -222,8 +296,6 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
     int sP[2];
     double wP[2];
     double nb = 1.0;                                              /* what today's push broadcasts; patient zero on day s, covid.h:339 */
-    double* hnP[2] = {W.hn[0], W.hn[1]};
-    double* heP[2] = {W.he[0], W.he[1]};
     int keLo[2], keHi[2];                                           /* source days with a capacity correction */
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -237,7 +309,7 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
     double* const dsDst = hiHalf ? W.d0 : W.d1;
     const double wBoth = hiHalf ? wP[1] : wP[0];
     const double* const kLane = lagTab + dayInBlk * MCMC_WV_KROW;  /* the lane's row of lag (its day - day t of the block) is kLane + (B-1-t) rows */
-    const double ng0S = lds.Rneg[0], ng0R = lds.Rneg[1], ng0D = lds.Rneg[2];      /* FromSerious at lag 0: today's own sums */
+    const double ng0S = M.Rneg[0], ng0R = M.Rneg[1], ng0D = M.Rneg[2];            /* FromSerious at lag 0: today's own sums */
     for (int k = (int)lane; k < W.histLen; k += MCMC_WAVE) {
         W.hn[0][k] = 0.0; W.he[0][k] = 0.0; W.hn[1][k] = 0.0; W.he[1][k] = 0.0;
     }
@@ -247,93 +319,97 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
 #pragma unroll 1
     for (int blk = 0; sP[1] + blk * MCMC_WV_B < horizon; ++blk) {
         const int j0P[2] = {sP[0] + blk * MCMC_WV_B, sP[1] + blk * MCMC_WV_B};
-        /* ---------- phase A: sources k < j0 (entries >= j0 of the history are still zero).  Tile rows m < 8: the
-         * block's days 0..15 at lag L; rows m >= 8: its days 16..31, i.e. the same source day at lag L + 16.  The
-         * table operand is the same for both passes, the history operand is each pass's own.  Lag groups whose
-         * source days carry corrections in EITHER pass form one range of lags (a correction of zero changes
-         * nothing), so the groups split into three runs -- plain, with corrections, plain -- each a tight loop
-         * of its own with both tiles in fixed registers. */
-        double4_t c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
+        const int iB = (hiHalf ? j0P[1] : j0P[0]) + dayInBlk;                   /* the lane's day */
+        /* ---------- phase A: sources k < j0, by descending lag (= ascending source day, the reference's order,
+         * covid.h:376-386).  Lane l owns the seven sums of ITS day; at lag L its source day is iB - L.  Entries >= j0
+         * of the history are still zero (phase B stores them later), entries below the first day are zero pads,
+         * so neither the in-block sources nor the days before patient zero need a mask.  The lags 1 .. 32 blk + 32
+         * (the top one only meets zero pads) go in groups of 16: lane n of every row reads the table at lag
+         * (top - n), DPP broadcasts it.  Groups that hold a source day with a capacity correction in EITHER pass
+         * take the form with the correction's operations (a correction of zero changes nothing). */
+        double Sx[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (blk > 0) {
-            const int Lhi = blk * MCMC_WV_B + (MCMC_WV_T - 1);
-            const int Loff = (m >> 3) * MCMC_WV_T, col = m & 7;
-            const double* hnB0 = hnP[0] + MCMC_WV_HLO + j0P[0] + n;   /* source day of lag L: j0 + n - L */
-            const double* hnB1 = hnP[1] + MCMC_WV_HLO + j0P[1] + n;
             int eLo = 0x7fffffff, eHi = -1;                          /* the lags with corrections, both passes */
 #pragma unroll
             for (int p = 0; p < 2; ++p)
                 if (keHi[p] >= keLo[p]) {
                     eLo = min(eLo, j0P[p] - keHi[p]);
-                    eHi = max(eHi, j0P[p] + (MCMC_WV_T - 1) - keLo[p]);
+                    eHi = max(eHi, j0P[p] + (MCMC_WV_B - 1) - keLo[p]);
                 }
-            const bool anyE = eHi >= eLo && eHi >= 1;
-            int L0 = Lhi;
-            auto plain_run = [&](int stop) {                         /* the groups with L0 >= stop */
-                if (L0 < stop) return;
-                /* operands of the NEXT group are requested before the current group's matrix instructions are issued */
-                double aN = lds.Rpos[min(max(L0 - kk, 0) + Loff, rowsM1) * 8 + col];
-                double bN0 = hnB0[-(L0 - kk)], bN1 = hnB1[-(L0 - kk)];
+            const double* const hN = hnDst + iB;                     /* source day of lag L: hN[-L] */
+            const double* const hE = heDst + iB;
+            struct LagOps { double t[7]; double h[MCMC_WV_T]; };
+            auto load_ops = [&](int top, LagOps& o) {
+                const double* tp = I.rt + min(top - n16, rowsM1);
+#pragma unroll
+                for (int c = 0; c < 7; ++c) o.t[c] = tp[c * I.rows];
+                const double* hp = hN - top;
+#pragma unroll
+                for (int j = 0; j < MCMC_WV_T; ++j) o.h[j] = hp[j];
+            };
+            auto run_plain = [&](const LagOps& o) {
+                pc.count(PH_NCHUNK, 1);
+                wave_lags8_lo(Sx, o.t, o.h);
+                wave_lags8_hi(Sx, o.t, o.h + 8);
+            };
+            auto run_e = [&](int top, const LagOps& o) {
+                pc.count(PH_NCHUNK_E, 1);
+                const int lagN = top - n16;
+                const double* tp = I.rt + min(lagN, rowsM1) + 7 * I.rows;
+                const double q[3] = {tp[0], tp[I.rows], tp[2 * I.rows]};
+                const double m = lagN < M.nLagRows ? 1.0 : 0.0;
+                double e[MCMC_WV_T];
+                const double* ep = hE - top;
+#pragma unroll
+                for (int j = 0; j < MCMC_WV_T; ++j) e[j] = ep[j];
+                wave_lags4_e<0>(Sx, o.t, q, m, o.h, e);
+                wave_lags4_e<4>(Sx, o.t, q, m, o.h + 4, e + 4);
+                wave_lags4_e<8>(Sx, o.t, q, m, o.h + 8, e + 8);
+                wave_lags4_e<12>(Sx, o.t, q, m, o.h + 12, e + 12);
+            };
+            /* The groups (tops 32 blk + 32, ..., 32, 16) form three runs -- plain, with corrections, plain -- each a
+             * tight loop of its own.  A plain run takes two groups per trip, each one's operands requested while the
+             * other's multiply-adds run; a run of odd length starts with a single group. */
+            int top = MCMC_WV_B * blk + MCMC_WV_B;
+            int eTop = 0, eBot = 1;                                  /* tops of the groups with corrections: eTop >= top' >= eBot */
+            if (eHi >= eLo) {
+                eTop = min(top, (eHi + MCMC_WV_T - 1) / MCMC_WV_T * MCMC_WV_T);         /* the group that holds lag eHi */
+                eBot = max((max(eLo, 1) + MCMC_WV_T - 1) / MCMC_WV_T * MCMC_WV_T, MCMC_WV_T);
+            }
+            LagOps oa, ob;
+            auto plain_run = [&](int stop) {                         /* the groups with stop <= top' <= top */
+                if (top < stop) return;
+                load_ops(top, oa);
+                if (((top - stop) / MCMC_WV_T) % 2 == 0) {           /* odd number of groups */
+                    run_plain(oa);
+                    top -= MCMC_WV_T;
+                    if (top < stop) return;
+                    load_ops(top, oa);
+                }
 #pragma unroll 1
-                for (; L0 >= stop; L0 -= 4) {
-                    const double a = aN, b0 = bN0, b1 = bN1;
-                    const int Ln = L0 - 4 - kk;                      /* below lag 1 the history operand is zero anyway */
-                    aN = lds.Rpos[min(max(Ln, 0) + Loff, rowsM1) * 8 + col];
-                    bN0 = hnB0[-max(Ln, -3)];
-                    bN1 = hnB1[-max(Ln, -3)];
-                    pc.count(PH_NCHUNK, 2);
-                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, c1, 0, 0, 0);
+                for (; top >= stop; top -= 2 * MCMC_WV_T) {
+                    load_ops(top - MCMC_WV_T, ob);
+                    run_plain(oa);
+                    load_ops(max(top - 2 * MCMC_WV_T, MCMC_WV_T), oa);   /* the last trip's is not used */
+                    run_plain(ob);
                 }
             };
-            plain_run(anyE ? max(eHi + 4, 1) : 1);                   /* a plain group has L0 - 3 > eHi */
-            if (anyE) {
-                /* one lag per matrix instruction, the K slots holding the source day's three operations in the
-                 * reference's order: n_k R_c[L]; + e_k (deaths: the flat add() of covid.h:387-391, cut after
-                 * traj.nDays lags like project()); - e_k x the three FromSerious curves; nothing.  What a lane
-                 * feeds depends on its slot only: */
-                const double* eTab = kk == 0 ? lds.Rpos : lds.Rneg;
-                const int eStride = kk == 0 ? 8 : 4;
-                const int eOff = kk == 0 ? col : kk == 1 ? 3 : min(max(col - A_SER, 0), 2);
-                const bool eValid = kk == 0 || (kk == 1 && col == A_DEAD) || (kk == 2 && col >= A_SER && col <= A_DEAD);
-                const double* eH0 = (kk == 0 ? hnP[0] : heP[0]) + MCMC_WV_HLO + j0P[0] + n;
-                const double* eH1 = (kk == 0 ? hnP[1] : heP[1]) + MCMC_WV_HLO + j0P[1] + n;
-                const int Ltop = L0;
-                const int stop = max(eLo, 1);
-                while (L0 >= stop) L0 -= 4;                           /* the groups of this run */
-                const int Lbot = max(L0 + 1, 1);
-                pc.count(PH_NCHUNK_E, 2 * max(Ltop - Lbot + 1, 0));
+            plain_run(eTop >= eBot ? eTop + MCMC_WV_T : MCMC_WV_T);
+            if (eTop >= eBot) {
 #pragma unroll 1
-                for (int L = Ltop; L >= Lbot; --L) {
-                    const int Lr = min(L + Loff, rowsM1);
-                    const double t = eTab[Lr * eStride + eOff];
-                    const double x0 = eH0[-L], x1 = eH1[-L];
-                    const double ae = eValid ? t : 0.0;
-                    const double be0 = kk == 3 ? 0.0 : (kk == 2 ? -x0 : x0), be1 = kk == 3 ? 0.0 : (kk == 2 ? -x1 : x1);
-                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be0, c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be1, c1, 0, 0, 0);
+                for (; top >= eBot; top -= MCMC_WV_T) {
+                    load_ops(top, oa);
+                    run_e(top, oa);
                 }
-                plain_run(1);
+                plain_run(MCMC_WV_T);
             }
         }
         pc.stamp(PH_CHUNKS);
-        /* ---------- phase B: the block's days in order, both passes day for day.  The tiles hold (MI, HI, INC, MILD)[q]
-         * and (SER, REC, DEAD, -)[q] of day n and of day 16 + n in the lanes (q, n); two 4 x 4 transpositions of rows
-         * bring all seven sums of day (l & 31) of pass (l >> 5) into lane l.  From then on lane l's sums only
-         * change while its day is not over (the lag table holds zeros for the days that are), and whatever it
-         * computes from them on the days after its own it computes again, the same: so every lane runs the day
-         * arithmetic on every day, the lane whose day it is feeds the next push, and the results are stored once,
-         * from all lanes, after the block. */
-        double Sx[7];
-        {
-            double G[4] = {c0[0], c0[2], c1[0], c1[2]}, Hh[4] = {c0[1], c0[3], c1[1], c1[3]};
-            if (blk > 0) {                                                       /* the first block's are zeros */
-                wave_transpose4(G);
-                wave_transpose4(Hh);
-            }
-            Sx[0] = G[0]; Sx[1] = G[1]; Sx[2] = G[2]; Sx[3] = G[3];
-            Sx[4] = Hh[0]; Sx[5] = Hh[1]; Sx[6] = Hh[2];
-        }
-        const int iB = (hiHalf ? j0P[1] : j0P[0]) + dayInBlk;                   /* the lane's day */
+        /* ---------- phase B: the block's days in order, both passes day for day.  Lane l's sums only change while
+         * its day is not over (the lag table holds zeros for the days that are), and whatever it computes from
+         * them on the days after its own it computes again, the same: so every lane runs the day arithmetic on
+         * every day, the lane whose day it is feeds the next push, and the results are stored once, from all
+         * lanes, after the block. */
         const bool live = iB < horizon;                                          /* days beyond compute garbage nobody reads */
         /* the block's first day enters the history only now: phase A takes a source day k >= j0 for zero, which
          * keeps the in-block sources (phase B's) out of it without a mask.  nb of lane 31 / 63 is that day's n */
@@ -342,7 +418,7 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
         double capL, tbL;
         {
             const int iC = min(iB, M.simPad - 1);
-            capL = lds.capacity[iC];
+            capL = live ? lds.capacity[iC] : __builtin_inf();      /* a day beyond the horizon never has a correction */
             const int sg = lds.seg[iC];
             const double pcf = sg >= 0 ? xdisc[max(sg, 0)] : 1.0;
             double smoothbehavior = 1.0;
@@ -351,7 +427,6 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
         }
         double nn = 0.0, eL = 0.0, deadL = 0.0;
         bool hasE = false;
-        const unsigned long long liveMask = __builtin_amdgcn_ballot_w64(live);
         /* the lane's table row of a day is requested a day ahead: LDS latency stays off the sequential chain */
         struct LagRow { double2_t k01, k23, k45; double k6; };
         auto lag_row = [&](int t) {
@@ -380,8 +455,8 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
                  * +0 or the product -0 * x changes no sum (none of them is ever -0) */
                 const double overCapacity = vSER * M.probICU - capL;
                 const double extraDeaths = M.probLethal * overCapacity;
-                const unsigned long long gt = __builtin_amdgcn_fcmp(extraDeaths, 0.0, 2 /* ordered > */) & liveMask;
-                hasE = live && extraDeaths > 0;
+                const unsigned long long gt = __builtin_amdgcn_fcmp(extraDeaths, 0.0, 2 /* ordered > */);
+                hasE = extraDeaths > 0;
                 eL = hasE ? extraDeaths : 0.0;
                 const double ne = -eL;
                 vDEAD = vDEAD + eL;                                                 /* today's own sums */
@@ -393,8 +468,10 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const LdsVi
                 const double nSus = M.pop - vINC - vMILD - vMILD - vSER - vREC - vDEAD;
                 nn = tbL * nSus / M.pop * (lp.betaMild * vMI + lp.betaHigh * vHI);
                 /* the later days' sums: + e (deaths), then the projections.  Only the lanes whose day it is decide */
-                const unsigned long long today = (1ull << t) | (1ull << (32 + t));
-                if (gt & today) {
+                /* the branch stays behind the day's arithmetic, where the old values of the sums it changes are dead
+                 * (hipcc otherwise sinks the arithmetic below it and copies the three sums on the common path) */
+                asm volatile("" : "+v"(nn), "+v"(deadL), "+v"(eL));
+                if (((unsigned)gt | (unsigned)(gt >> 32)) & (1u << t)) {
                     const double e0 = readlane_f64(eL, t), e1 = readlane_f64(eL, 32 + t);
                     const double eb = hiHalf ? e1 : e0, neb = -eb;
                     const double2_t n01 = *(const double2_t*)(kr + 8), n23 = *(const double2_t*)(kr + 10);
@@ -568,9 +645,7 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, 
                                                       const double* __restrict__ betas,
                                                       const int* __restrict__ flags, int slot0) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
-    const LdsView lds = stage_lds(M, lds_raw, false, MCMC_WV_T);
-    const int ldsRows = lds_rows(M, false, MCMC_WV_T);
-    const double* lagTab = stage_wave_lags(lds, lds_raw, M, ldsRows);
+    const WaveImage I = stage_wave_image(M, lds_raw);
     const unsigned lane = threadIdx.x & (MCMC_WAVE - 1);
     const int waveInBlock = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / MCMC_WAVE));
     const int wavesPerBlock = (int)(blockDim.x / MCMC_WAVE);       /* 4, or fewer where the series leaves LDS for fewer slices */
@@ -649,7 +724,7 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, 
         pc.stamp(PH_RECORD);
         const bool behChanged = propose_wave(M, rnd, W, lane, stepsize, lp, llpNew);
         pc.stamp(PH_PROPOSE);
-        const double llm = eval_model_wave(M, lds, W, lp, lane, work, ldsRows, lagTab, pc);
+        const double llm = eval_model_wave(M, I, W, lp, lane, work, pc);
         double llp = 0.0;
         double delta = 0;                                           /* mcmc.h:604-606 */
         delta += -llModel + llm;

@@ -193,7 +193,7 @@ def test_wave_mapping_refuses_what_it_cannot_run(R11, R10):
         fast.set_mapping("wave")
     fast.set_chains(perturbed(fast.cfg, 8, 0.05)); assert fast.mapping() == "lane"
     fast.close()
-    long = H.CovidSampler(make_cfg(1200, R11, contract=1), R10)      # 365 days: 2 chains per workgroup; 560: 1; 1200: none fits
+    long = H.CovidSampler(make_cfg(1600, R11, contract=1), R10)      # 365 days: 4 chains per workgroup; 1200: 1; 1600: none fits
     with pytest.raises(H.McmcHipError, match="too long"):
         long.set_mapping("wave")
     long.set_chains(H.perturb_ics(CC.initial_params(long.cfg), 8, 0.01)); assert long.mapping() == "lane"
