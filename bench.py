@@ -302,7 +302,7 @@ def main():
                          "(State::perturb's rule, mcmc.h:306-314); default 0.01 as SURVEY 8d, 0.001 with --regions")
     ap.add_argument("--mapping", default="auto", choices=["auto", "lane", "wave"],
                     help="chains onto the GPU: one per lane, one per wavefront (small ensembles), or the library's choice "
-                         "(wave up to 4096 chains); no effect on results (include/mcmc_hip.h, mcmc_hip_set_mapping)")
+                         "(wave up to 16384 chains); no effect on results (include/mcmc_hip.h, mcmc_hip_set_mapping)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-leg", action="store_true", help="skip the FP32 fast-mode leg (N=1 only)")
     ap.add_argument("--no-strict-leg", action="store_true", help="skip the strict (no FMA contraction) leg (N=1 only)")

@@ -170,8 +170,8 @@ int mcmc_hip_set_precision(mcmc_hip_ctx* ctx, int32_t mode);
  *         the wave's lanes and the FP64 matrix instruction; a chain's state lives in LDS for the length of a
  *         launch.  For small ensembles -- BASELINE.json configs[1]'s 1 024 chains are 16 wavefronts under LANE
  *         and 1 024 under WAVE.  Needs cfg.contract = 1, the double-precision mode, the single-region State and
- *         a series that fits a wave's LDS slice (about 1 000 data days at the default table sizes); set_mapping(WAVE) fails otherwise.
- *   AUTO  (default) WAVE where possible for ensembles of at most 4 096 chains, else LANE.
+ *         a series that fits a wave's LDS slice (about 1 200 data days); set_mapping(WAVE) fails otherwise.
+ *   AUTO  (default) WAVE where possible for ensembles of at most 16 384 chains, else LANE.
  * May be called at any time; it takes effect from the next launch.  get_mapping: what the next launch uses. */
 #define MCMC_HIP_MAPPING_AUTO 0
 #define MCMC_HIP_MAPPING_LANE 1

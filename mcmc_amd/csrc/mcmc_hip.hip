@@ -28,7 +28,7 @@
 #define MCMC_STEPS_PER_LAUNCH 16   /* MH steps one mh_step_kernel launch advances every chain by */
 #endif
 #ifndef MCMC_WAVE_AUTO_MAX
-#define MCMC_WAVE_AUTO_MAX 4096    /* MCMC_HIP_MAPPING_AUTO: ensembles up to this many chains take one chain per wavefront (tools/mapping_sweep.sh) */
+#define MCMC_WAVE_AUTO_MAX 16384   /* MCMC_HIP_MAPPING_AUTO: ensembles up to this many chains take one chain per wavefront (tools/mapping_sweep.sh) */
 #endif
 #ifndef MCMC_T_DERIVE
 #define MCMC_T_DERIVE 4    /* the derive kernel is not a hot path: small block, short compile */

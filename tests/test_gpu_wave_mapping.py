@@ -164,8 +164,8 @@ def test_wave_mapping_on_the_365_day_series_and_auto_threshold(R11, R10):
     s = H.CovidSampler(make_cfg(40, R11, contract=1, **SMALL), R10)
     c40 = s.cfg
     s.set_chains(perturbed(c40, 10, 0.05)); assert s.mapping() == "wave"
-    s.set_chains(H.perturb_ics(CC.initial_params(c40), 4097, 0.01)); assert s.mapping() == "lane"
-    s.set_chains(H.perturb_ics(CC.initial_params(c40), 4096, 0.01)); assert s.mapping() == "wave"
+    s.set_chains(H.perturb_ics(CC.initial_params(c40), 16385, 0.01)); assert s.mapping() == "lane"
+    s.set_chains(H.perturb_ics(CC.initial_params(c40), 16384, 0.01)); assert s.mapping() == "wave"
     s.close()
 
 
