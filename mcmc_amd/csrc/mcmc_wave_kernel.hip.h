@@ -264,6 +264,37 @@ __device__ __forceinline__ double ordered_sum(double sum, const double* t, int c
     return sum;
 }
 
+/* x / pop (covid.h:461).  hipcc's double division is: scale both operands if an exponent is extreme (v_div_scale),
+ * y = two Newton steps on v_rcp of the denominator, q = x y, r = fma(-pop, q, x), fma(r, y, q), un-scale (v_div_fmas),
+ * special cases (v_div_fixup).  pop never changes, so y is formed once per launch (wave_rcp_pop, the same
+ * instructions), and where no scaling happens -- frexp exponent of x in [ELO, EHI], pop of ordinary size -- the
+ * remaining four instructions ARE the division, bit for bit.  eval_model_wave checks every numerator it used and
+ * has the whole evaluation redone with the compiler's division if one fell outside (never, on a sane epidemic). */
+#define MCMC_WV_DIV_ELO (-900)
+#define MCMC_WV_DIV_EHI 700
+__device__ __forceinline__ double wave_rcp_pop(double pop) {
+    double y = __builtin_amdgcn_rcp(pop);
+    double e = __builtin_fma(-pop, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-pop, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    return y;
+}
+__device__ __forceinline__ bool wave_fast_div_ok(double pop) {
+    const int ex = __builtin_amdgcn_frexp_exp(pop);
+    return ex > -100 && ex < 100;
+}
+template <bool FASTDIV>
+__device__ __forceinline__ double wave_div_pop(double x, double pop, double rcpPop) {
+    if constexpr (FASTDIV) {
+        const double q = x * rcpPop;
+        const double r = __builtin_fma(-pop, q, x);
+        return __builtin_amdgcn_div_fixup(__builtin_fma(r, rcpPop, q), pop, x);
+    } else {
+        return x / pop;
+    }
+}
+
 /*
  * DiseaseSpread::eval (covid.h:325-496) of the parameter vector W.xp for the chain of this WAVE.  Every lane
  * returns the same loglike.  Same operations on every accumulator, in the same order, as eval_model<T, true>.
@@ -275,8 +306,10 @@ __device__ __forceinline__ double ordered_sum(double sum, const double* t, int c
  * instruction, tools/ubench/mfma_f64.hip), and the two sequential day chains fill each other's latency gaps.
  * The day loop is straight-line for that reason (its one branch, a capacity correction today, is wave-uniform).
  */
+template <bool FASTDIV>
 __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveImage& I, const WaveSlice& W,
-                                                  const LaneScalars& lp, unsigned lane, WorkCount& work, PhaseClock& pc) {
+                                                  const LaneScalars& lp, unsigned lane, WorkCount& work, PhaseClock& pc,
+                                                  double rcpPop, bool& redo) {
     const LdsView& lds = I.lds;
     const double* const lagTab = I.lagTab;
     const int md = M.md;
@@ -316,6 +349,7 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
     wave_sync();
     pc.stamp(PH_SETUP);
 
+    unsigned long long redoMask = 0;
 #pragma unroll 1
     for (int blk = 0; sP[1] + blk * MCMC_WV_B < horizon; ++blk) {
         const int j0P[2] = {sP[0] + blk * MCMC_WV_B, sP[1] + blk * MCMC_WV_B};
@@ -425,7 +459,7 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
             if (iC >= md) smoothbehavior = pcf * W.xp[min(max(iC - md, 0), M.nB - 1)];
             tbL = pcf * smoothbehavior;
         }
-        double nn = 0.0, eL = 0.0, deadL = 0.0;
+        double nn = 0.0, eL = 0.0, deadL = 0.0, numL = 0.0;
         bool hasE = false;
         /* the lane's table row of a day is requested a day ahead: LDS latency stays off the sequential chain */
         struct LagRow { double2_t k01, k23, k45; double k6; };
@@ -466,7 +500,8 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
                 deadL = vDEAD;
                 /* tomorrow's new infections (covid.h:461-462); asymptomatic == mild buffer */
                 const double nSus = M.pop - vINC - vMILD - vMILD - vSER - vREC - vDEAD;
-                nn = tbL * nSus / M.pop * (lp.betaMild * vMI + lp.betaHigh * vHI);
+                numL = tbL * nSus;
+                nn = wave_div_pop<FASTDIV>(numL, M.pop, rcpPop) * (lp.betaMild * vMI + lp.betaHigh * vHI);
                 /* the later days' sums: + e (deaths), then the projections.  Only the lanes whose day it is decide */
                 /* the branch stays behind the day's arithmetic, where the old values of the sums it changes are dead
                  * (hipcc otherwise sinks the arithmetic below it and copies the three sums on the common path) */
@@ -501,6 +536,12 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
                 }
             }
         }
+        if constexpr (FASTDIV) {
+            /* did every division of this block stay where the short form is the long one?  (each lane's last numerator
+             * is its own day's; frexp gives 0 for zero, infinity and NaN, which v_div_fixup settles in both forms) */
+            const unsigned ex = (unsigned)(__builtin_amdgcn_frexp_exp(numL) - MCMC_WV_DIV_ELO);
+            redoMask |= __builtin_amdgcn_ballot_w64(live && ex > (unsigned)(MCMC_WV_DIV_EHI - MCMC_WV_DIV_ELO));
+        }
         pc.stamp(PH_DAYS);
         wave_sync();
     }
@@ -522,6 +563,7 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
         wave_sync();
     }
     pc.stamp(PH_LOGLIKE);
+    redo = redoMask != 0;
     return loglike;
 }
 
@@ -688,6 +730,8 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, 
     work.exec = pairs_g[MCMC_WAVE];
     const double rungBeta = S.chainBeta ? S.chainBeta[flat] : 1.0;
     int slot = slot0;
+    const bool fastDiv = wave_fast_div_ok(M.pop);
+    const double rcpPop = wave_rcp_pop(M.pop);
     PhaseClock pc;
     pc.start();
 
@@ -724,7 +768,17 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, 
         pc.stamp(PH_RECORD);
         const bool behChanged = propose_wave(M, rnd, W, lane, stepsize, lp, llpNew);
         pc.stamp(PH_PROPOSE);
-        const double llm = eval_model_wave(M, I, W, lp, lane, work, pc);
+        /* the short division first; the compiler's if a numerator left the range where the two are the same */
+        double llm;
+        {
+            const WorkCount work0 = work;
+            bool redo = !fastDiv;
+            if (fastDiv) llm = eval_model_wave<true>(M, I, W, lp, lane, work, pc, rcpPop, redo);
+            if (redo) {
+                work = work0;
+                llm = eval_model_wave<false>(M, I, W, lp, lane, work, pc, rcpPop, redo);
+            }
+        }
         double llp = 0.0;
         double delta = 0;                                           /* mcmc.h:604-606 */
         delta += -llModel + llm;

@@ -75,7 +75,8 @@ def test_wave_mapping_runs_the_same_chains_as_lane_and_oracle(R11, R10):
     lane.close(); wave.close()
 
 
-@pytest.mark.parametrize("case", ["overflow", "overflow_fixed_no_prior", "many_breakpoints", "delay_bounds", "plain_target"])
+@pytest.mark.parametrize("case", ["overflow", "overflow_fixed_no_prior", "many_breakpoints", "delay_bounds", "plain_target",
+                                  "tiny_behaviour"])
 def test_wave_mapping_on_the_models_branches(R11, R10, case):
     kw, a, steps, target = dict(SMALL), 0.1, 30, ("temp", 1.0)
     if case == "overflow":                 # capacity corrections on many days (covid.h:413-429), switching on and off
@@ -90,10 +91,16 @@ def test_wave_mapping_on_the_models_branches(R11, R10, case):
         a = 0.02
     elif case == "delay_bounds":
         cfg = make_cfg(45, R11, contract=1, **kw)
+    elif case == "tiny_behaviour":         # numerators of the day's division down in the denormals: the wave kernel's short
+        cfg = make_cfg(44, R11, contract=1, **kw)          # division hands the evaluation over to the compiler's (wave_div_pop)
     else:
         cfg = make_cfg(48, R11, contract=1, target_kind="plain", **kw)
         target = ("plain",)
     xs = perturbed(cfg, 66, a)
+    if case == "tiny_behaviour":
+        xs[::2, 3] = 1e-305
+        xs[1::4, 10] = 3e-300
+        xs[2::4, 7] = 0.0
     if case == "delay_bounds":             # first days at both ends of [5, maxDelay]: start = 7 and 0, frac = 0 and not
         xs[::3, -1] = 5.0
         xs[1::3, -1] = 12.0
