@@ -423,8 +423,10 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
 #pragma unroll 1
                 for (; top >= stop; top -= 2 * MCMC_WV_T) {
                     load_ops(top - MCMC_WV_T, ob);
+                    __builtin_amdgcn_sched_barrier(0);               /* each request stays in front of the other group's multiply-adds */
                     run_plain(oa);
                     load_ops(max(top - 2 * MCMC_WV_T, MCMC_WV_T), oa);   /* the last trip's is not used */
+                    __builtin_amdgcn_sched_barrier(0);
                     run_plain(ob);
                 }
             };
@@ -460,7 +462,6 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
             tbL = pcf * smoothbehavior;
         }
         double nn = 0.0, eL = 0.0, deadL = 0.0, numL = 0.0;
-        bool hasE = false;
         /* the lane's table row of a day is requested a day ahead: LDS latency stays off the sequential chain */
         struct LagRow { double2_t k01, k23, k45; double k6; };
         auto lag_row = [&](int t) {
@@ -490,8 +491,7 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
                 const double overCapacity = vSER * M.probICU - capL;
                 const double extraDeaths = M.probLethal * overCapacity;
                 const unsigned long long gt = __builtin_amdgcn_fcmp(extraDeaths, 0.0, 2 /* ordered > */);
-                hasE = extraDeaths > 0;
-                eL = hasE ? extraDeaths : 0.0;
+                eL = extraDeaths > 0 ? extraDeaths : 0.0;
                 const double ne = -eL;
                 vDEAD = vDEAD + eL;                                                 /* today's own sums */
                 vSER = __builtin_fma(ne, ng0S, vSER);
@@ -501,12 +501,19 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
                 /* tomorrow's new infections (covid.h:461-462); asymptomatic == mild buffer */
                 const double nSus = M.pop - vINC - vMILD - vMILD - vSER - vREC - vDEAD;
                 numL = tbL * nSus;
-                nn = wave_div_pop<FASTDIV>(numL, M.pop, rcpPop) * (lp.betaMild * vMI + lp.betaHigh * vHI);
-                /* the later days' sums: + e (deaths), then the projections.  Only the lanes whose day it is decide */
-                /* the branch stays behind the day's arithmetic, where the old values of the sums it changes are dead
-                 * (hipcc otherwise sinks the arithmetic below it and copies the three sums on the common path) */
-                asm volatile("" : "+v"(nn), "+v"(deadL), "+v"(eL));
-                if (((unsigned)gt | (unsigned)(gt >> 32)) & (1u << t)) {
+                const double perCapita = wave_div_pop<FASTDIV>(numL, M.pop, rcpPop), force = lp.betaMild * vMI + lp.betaHigh * vHI;
+                nn = perCapita * force;
+                double nn2 = 0.0;                                                   /* the same product in a second register: see below */
+                if (half == 0)      /* (hipcc pads an asm's outputs like any VALU write: the two wait states before v_permlane16_swap are its) */
+                    asm("v_mul_f64 %0, %1, %2" : "=v"(nn2) : "v"(perCapita), "v"(force));
+                /* The later days' sums: + e (deaths), then the projections.  The test is "a correction in ANY lane" (one
+                 * branch on the compare's mask): a lane whose day has passed keeps its correction in the mask, so from
+                 * a block's first correction on the branch is taken for nothing on some days -- today's e is zero
+                 * then and changes nothing (measured against a test of today's two lanes: 4 % faster on configs[1]).
+                 * The branch stays behind the day's arithmetic, where the old values of the sums it changes are dead
+                 * (hipcc otherwise sinks the arithmetic below it and copies the three sums on the common path). */
+                asm volatile("" : "+v"(nn), "+v"(nn2), "+v"(deadL), "+v"(eL));
+                if (gt) {
                     const double e0 = readlane_f64(eL, t), e1 = readlane_f64(eL, 32 + t);
                     const double eb = hiHalf ? e1 : e0, neb = -eb;
                     const double2_t n01 = *(const double2_t*)(kr + 8), n23 = *(const double2_t*)(kr + 10);
@@ -515,8 +522,12 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
                     Sx[5] = __builtin_fma(neb, n01[1], Sx[5]);
                     Sx[6] = __builtin_fma(neb, n23[0], Sx[6]);
                 }
-                /* tomorrow's push reads lane u of every row: the second half's lanes get the first half's number */
-                nb = half == 0 ? row_pair_bcast<true>(nn) : nn;
+                /* tomorrow's push reads lane u of every row: the second half's lanes get the first half's number (their
+                 * own nn is not theirs yet).  v_permlane16_swap exchanges between two registers, hence the second product */
+                if (half == 0) {
+                    swap16_f64(nn, nn2);
+                }
+                nb = nn;
             }
         }
         nb = row_pair_bcast<false>(nn);                                             /* day 31's, for the next block's day 0 */
@@ -526,7 +537,7 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
             if (iB >= md && iB - md < M.nData) dsDst[iB - md] = wBoth * deadL;      /* covid.h:475,484 */
         }
         {
-            const unsigned long long hm = __builtin_amdgcn_ballot_w64(hasE);
+            const unsigned long long hm = __builtin_amdgcn_ballot_w64(eL > 0);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const unsigned m32 = (unsigned)(hm >> (32 * p));
