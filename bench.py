@@ -263,6 +263,8 @@ def side_leg(cfg, R, device, start, first_id, args, precision, contract):
     cfg2 = dict(cfg)
     cfg2["contract"] = contract
     s = H.CovidSampler(cfg2, R, device, precision=precision)
+    if precision == "f64":
+        s.set_mapping(args.mapping)                  # the main leg's; the fast mode runs one chain per lane only
     s.set_chains(start[0], stepsizes=start[1], first_chain_id=first_id)
     steps = max(STEPS_PER_LAUNCH, args.steps // 2 // STEPS_PER_LAUNCH * STEPS_PER_LAUNCH)
     s.step(args.warmup, 1.0, True)
@@ -274,12 +276,13 @@ def side_leg(cfg, R, device, start, first_id, args, precision, contract):
     t1 = s.last_timing()
     pairs, pairs_exec = s.pair_count(), s.executed_pair_count()
     n = start[0].shape[0]
+    mapping = s.mapping()
     s.close()
     ksec, launches = t1["step_kernel_s"] - t0["step_kernel_s"], t1["launches"] - t0["launches"]
     flops = 16.0 * pairs + (10.0 * cfg["n_data"] + 7.0 * cfg["nB"]) * n * steps
     return {"value": n * steps / wall, "unit": "MH steps/s", "steps": steps, "ms_per_step": 1e3 * wall / steps,
             "kernel_ms_per_launch": 1e3 * ksec / max(launches, 1), "achieved": flops / ksec / 1e12,
-            "executed_tflops": 14.0 * pairs_exec / ksec / 1e12, "unit_roofline": "TFLOP/s"}
+            "executed_tflops": 14.0 * pairs_exec / ksec / 1e12, "unit_roofline": "TFLOP/s", "mapping": mapping}
 
 
 def main():

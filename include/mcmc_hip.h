@@ -165,12 +165,12 @@ int mcmc_hip_set_precision(mcmc_hip_ctx* ctx, int32_t mode);
  * chain, mcmc.h:1494-1508) and no effect on any result: both mappings execute the same operations in the same
  * order and give the same bits (tests/test_gpu_wave_mapping.py).
  *   LANE  one chain per lane, 64 chains per wavefront in lockstep: north_star's mapping, the one that fills the
- *         chip from about 16 k chains on and is the faster one from about 6 k.
- *   WAVE  one chain per WAVEFRONT (mcmc_wave_kernel.hip.h): a block of 16 days x 7 compartments is spread over
- *         the wave's lanes and the FP64 matrix instruction; a chain's state lives in LDS for the length of a
- *         launch.  For small ensembles -- BASELINE.json configs[1]'s 1 024 chains are 16 wavefronts under LANE
- *         and 1 024 under WAVE.  Needs cfg.contract = 1, the double-precision mode, the single-region State and
- *         a series that fits a wave's LDS slice (about 1 200 data days); set_mapping(WAVE) fails otherwise.
+ *         chip from 64 k chains on and is the faster one from about 17 k (200 days) to 24 k (365 days).
+ *   WAVE  one chain per WAVEFRONT (mcmc_wave_kernel.hip.h): every lane owns one day of a 32-day block of one of
+ *         the two integer-shift passes; a chain's state lives in LDS for the length of a launch.  For small
+ *         ensembles -- BASELINE.json configs[1]'s 1 024 chains are 16 wavefronts under LANE and 1 024 under
+ *         WAVE.  Both arithmetic modes (cfg.contract).  Needs the double-precision mode, the single-region State
+ *         and a series that fits a wave's LDS slice (about 1 200 data days); set_mapping(WAVE) fails otherwise.
  *   AUTO  (default) WAVE where possible for ensembles of at most 16 384 chains, else LANE.
  * May be called at any time; it takes effect from the next launch.  get_mapping: what the next launch uses. */
 #define MCMC_HIP_MAPPING_AUTO 0

@@ -324,7 +324,6 @@ bool wave_mapping_possible(const mcmc_hip_ctx* c, const char** why) {
     const char* w = nullptr;
     if (c->multi) w = "the multi-region model runs one chain per lane only";
     else if (c->precision != MCMC_HIP_PRECISION_F64) w = "the fast mode runs one chain per lane only";
-    else if (!c->cfg.contract) w = "one chain per wavefront needs cfg.contract = 1 (its matrix instruction is a fused multiply-add)";
     else if (wave_lds_bytes(c->M, c->dim, 1) > kLdsMax) w = "the series is too long for a chain's slice of LDS";
     if (why) *why = w;
     return w == nullptr;
@@ -343,8 +342,13 @@ int launch_wave_steps(mcmc_hip_ctx* c, int nSteps, const double* dBetas, const i
     size_t shmem = wave_lds_bytes(c->M, c->dim, wpb);
     if (shmem > kLdsMax) return fail(MCMC_HIP_EINVAL, "the series is too long for a chain's slice of LDS (%zu B > %zu B)", shmem, kLdsMax);
     if (grid <= (unsigned)c->nCU && shmem < kLdsSolo) shmem = kLdsSolo;      /* one workgroup per CU while CUs are idle */
-    HIP_TRY(hipFuncSetAttribute((const void*)mh_step_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(mh_step_wave_kernel, dim3(grid), dim3(wpb * MCMC_WAVE), shmem, c->stream, c->M, c->S, nSteps, dBetas, dFlags, slot0);
+    if (c->cfg.contract) {
+        HIP_TRY(hipFuncSetAttribute((const void*)mh_step_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(mh_step_wave_kernel<true>, dim3(grid), dim3(wpb * MCMC_WAVE), shmem, c->stream, c->M, c->S, nSteps, dBetas, dFlags, slot0);
+    } else {
+        HIP_TRY(hipFuncSetAttribute((const void*)mh_step_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(mh_step_wave_kernel<false>, dim3(grid), dim3(wpb * MCMC_WAVE), shmem, c->stream, c->M, c->S, nSteps, dBetas, dFlags, slot0);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -3,34 +3,38 @@
  * WAVEFRONT instead of one chain per lane (EXTENSION beside north_star's mapping; same arithmetic, same bits).
  *
  * Why: with one chain per lane BASELINE configs[1] (1 024 chains x 200 days) is 16 wavefronts on a chip of
- * 1 024 SIMDs.  The model's only parallelism inside one chain is (destination day) x (compartment): every
- * accumulator buf_c[j] receives its addends n_k * R_c[j-k] in ascending source day k (that order is the
- * reference's, covid.h:376-386, and fixes the bits), but the 7 compartments and the days of a block are
- * independent of each other.  This kernel gives a chain a whole wavefront and spreads a block of 16 days x 7
- * compartments over it:
+ * 1 024 SIMDs.  Inside one chain every accumulator buf_c[j] receives its addends n_k * R_c[j-k] in ascending
+ * source day k (that order is the reference's, covid.h:376-386, and fixes the bits), but the days of a block and
+ * the two integer-shift passes of an evaluation (covid.h:335) are independent of each other.  So LANE l OWNS ONE
+ * DAY of a 32-day block of ONE pass -- pass l >> 5, day l & 31 -- and keeps that day's seven sums in registers;
+ * both passes run in lockstep, block for block and day for day.
  *
- *   phase A  (sources before the block)   C[c][t] = sum over lags L of R_c[L] * n_{j0+t-L}  is a matrix product
- *            with A[m = c][k = L] = table, B[k = L][n = t] = history (Toeplitz), and v_mfma_f64_16x16x4_f64 is,
- *            bit for bit, the chain fma(a3,b3,fma(a2,b2,fma(a1,b1,fma(a0,b0,C)))) (tools/ubench/mfma_f64.hip:
- *            0 mismatches) -- with the K slots holding DESCENDING lags that is ascending source days, the order
- *            the parity bar needs.  One MFMA = 4 lags x 16 days x 7 compartments; both operands come from LDS
- *            (the workgroup's table image, the wave's own history).  Lags whose source day carries a hospital-
- *            capacity correction (covid.h:413-429) go one lag per MFMA, the K slots holding that source day's
- *            three operations in the reference's order: n_k * R_c[L], then + e_k (deaths), then - e_k * FromSerious[L].
+ *   phase A  (sources before the block)   at lag L lane l needs R_c[L] * n[its day - L]: the table value is
+ *            wave-uniform, the history value the lane's own.  The lags go in groups of 16: lane n of every 16-lane
+ *            row reads the table (curve-major in LDS) at lag (top - n), and v_fmac_f64_dpp row_newbcast:j
+ *            multiplies lane j's table value with the lane's own history value of lag (top - j).  Descending lags
+ *            are ascending source days.  Groups whose source days carry a hospital-capacity correction
+ *            (covid.h:413-429) do that day's three operations after its seven projections, in the reference's
+ *            order: n_k * R_c[L], then + e_k (deaths), then - e_k * FromSerious[L].
  *   phase B  (the block's 32 days in order; the feedback n_{i+1} = f(buffers[i]) is sequential, covid.h:461-462)
- *            the sums are transposed once per block (v_permlane16_swap / v_permlane32_swap) so that ONE LANE holds
- *            all seven sums of ONE day -- lane l: pass l >> 5, day l & 31 of the block -- and that lane runs the
- *            day's scalar arithmetic where the numbers are.  Today's n_i reaches the later days' sums with one
- *            v_fmac_f64_dpp row_newbcast per compartment (the multiplicand is the lane's table row of lag
- *            (its day - today), a row of zeros once its day is over), so a day costs ~50 instructions for both
- *            passes together instead of fetching seven sums into every lane.
+ *            today's n_i reaches the later days' sums with one v_fmac_f64_dpp row_newbcast per compartment (the
+ *            multiplier is the lane's row of a small lag table: lag (its day - today), a row of zeros once its
+ *            day is over), and every lane runs the day's scalar arithmetic on its own seven sums -- the lane
+ *            whose day it is produces the number the next push broadcasts, a lane whose day has passed
+ *            recomputes what it computed then.  Nothing is selected or stored inside the loop; after the block
+ *            all 64 lanes store their day's results at once.  ~42 instructions per day for both passes together.
+ *
+ * (The first version ran phase A on the FP64 matrix cores -- v_mfma_f64_16x16x4_f64 is bit for bit the chain
+ * fma(a3,b3,fma(a2,b2,fma(a1,b1,fma(a0,b0,C)))), tools/ubench/mfma_f64.hip -- at 7.0 M steps/s on configs[1];
+ * gfx950 issues that instruction every 149 cycles, the vector form here runs 18.6 M.  DESIGN.md 4b has the history.)
  *
  * Everything a chain touches during a launch -- parameter vector, proposal, both histories, weighted deaths --
  * lives in the wave's slice of LDS; HBM is read at the start of a launch and written at its end (and by
  * recording).  The proposal's behaviour nodes, the prior's and the likelihood's terms are computed one per
- * lane and summed in the reference's order.  Only FP64 with FMA contraction (cfg.contract = 1: an MFMA is
- * fused), only the single-region State.  The host picks the mapping by ensemble size (mcmc_hip_set_mapping);
- * tests/test_gpu_wave_mapping.py holds it bit-exact to the oracle AND to the chain-per-lane kernel.
+ * lane and summed in the reference's order.  Both arithmetic modes (template FUSE = cfg.contract; without
+ * contraction a term is a DPP move, a multiply and an add), only FP64, only the single-region State.  The host
+ * picks the mapping by ensemble size (mcmc_hip_set_mapping); tests/test_gpu_wave_mapping.py holds it bit-exact to
+ * the oracle AND to the chain-per-lane kernel.
  */
 #pragma once
 
@@ -212,6 +216,72 @@ __device__ __forceinline__ void wave_lags4_e(double (&S)[7], const double (&t)[7
     else MCMC_WV_LAGS4_E(12, 13, 14, 15);
 }
 
+/* cfg.contract = 0: every term is a multiply and an add (covid.h:384 as the C++ abstract machine has it).  The
+ * DPP form exists for the fused instruction only (v_mul_f64 / v_add_f64 take no DPP source on gfx950), so the
+ * broadcast is a v_mov_b64_dpp of its own: three instructions per term instead of one. */
+template <int L>
+__device__ __forceinline__ void bcast7(double (&b)[7], const double (&t)[7]) {
+#define MCMC_WV_MOV(D, S) "v_mov_b64_dpp " D ", " S " row_newbcast:%[lane] row_mask:0xf bank_mask:0xf\n\t"
+    asm("s_nop 1\n\t" MCMC_WV_MOV("%0", "%7") MCMC_WV_MOV("%1", "%8") MCMC_WV_MOV("%2", "%9") MCMC_WV_MOV("%3", "%10")
+        MCMC_WV_MOV("%4", "%11") MCMC_WV_MOV("%5", "%12") MCMC_WV_MOV("%6", "%13")
+        : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6])
+        : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), [lane] "n"(L));
+}
+template <int L>
+__device__ __forceinline__ double bcast1(double v) {
+    double o;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%[lane] row_mask:0xf bank_mask:0xf" : "=&v"(o) : "v"(v), [lane] "n"(L));
+    return o;
+}
+#undef MCMC_WV_MOV
+template <int L>
+__device__ __forceinline__ void strict_lag(double (&S)[7], const double (&t)[7], double h) {
+    double b[7];
+    bcast7<L>(b, t);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) S[c] = S[c] + h * b[c];
+}
+template <int L>
+__device__ __forceinline__ void strict_lag_e(double (&S)[7], const double (&t)[7], const double (&q)[3], double m, double h, double e) {
+    strict_lag<L>(S, t, h);
+    const double bm = bcast1<L>(m), b0 = bcast1<L>(q[0]), b1 = bcast1<L>(q[1]), b2 = bcast1<L>(q[2]);
+    S[6] = S[6] + e * bm;
+    S[4] = S[4] + e * b0;
+    S[5] = S[5] + e * b1;
+    S[6] = S[6] + e * b2;
+}
+__device__ __forceinline__ void strict_lags16(double (&S)[7], const double (&t)[7], const double* h) {
+    strict_lag<0>(S, t, h[0]); strict_lag<1>(S, t, h[1]); strict_lag<2>(S, t, h[2]); strict_lag<3>(S, t, h[3]);
+    strict_lag<4>(S, t, h[4]); strict_lag<5>(S, t, h[5]); strict_lag<6>(S, t, h[6]); strict_lag<7>(S, t, h[7]);
+    strict_lag<8>(S, t, h[8]); strict_lag<9>(S, t, h[9]); strict_lag<10>(S, t, h[10]); strict_lag<11>(S, t, h[11]);
+    strict_lag<12>(S, t, h[12]); strict_lag<13>(S, t, h[13]); strict_lag<14>(S, t, h[14]); strict_lag<15>(S, t, h[15]);
+}
+__device__ __forceinline__ void strict_lags16_e(double (&S)[7], const double (&t)[7], const double (&q)[3], double m,
+                                                const double* h, const double* e) {
+    strict_lag_e<0>(S, t, q, m, h[0], e[0]); strict_lag_e<1>(S, t, q, m, h[1], e[1]);
+    strict_lag_e<2>(S, t, q, m, h[2], e[2]); strict_lag_e<3>(S, t, q, m, h[3], e[3]);
+    strict_lag_e<4>(S, t, q, m, h[4], e[4]); strict_lag_e<5>(S, t, q, m, h[5], e[5]);
+    strict_lag_e<6>(S, t, q, m, h[6], e[6]); strict_lag_e<7>(S, t, q, m, h[7], e[7]);
+    strict_lag_e<8>(S, t, q, m, h[8], e[8]); strict_lag_e<9>(S, t, q, m, h[9], e[9]);
+    strict_lag_e<10>(S, t, q, m, h[10], e[10]); strict_lag_e<11>(S, t, q, m, h[11], e[11]);
+    strict_lag_e<12>(S, t, q, m, h[12], e[12]); strict_lag_e<13>(S, t, q, m, h[13], e[13]);
+    strict_lag_e<14>(S, t, q, m, h[14], e[14]); strict_lag_e<15>(S, t, q, m, h[15], e[15]);
+}
+/* today's number, from lane srcLane of the lane's own row, times the lane's lag-table row, strict form */
+__device__ __forceinline__ void strict_push7(double (&S)[7], int srcLane, double nb, const double (&k)[7]) {
+    double b;
+    switch (srcLane) {                     /* a constant wherever this is called: the day loop is unrolled */
+        case 0: b = bcast1<0>(nb); break;   case 1: b = bcast1<1>(nb); break;   case 2: b = bcast1<2>(nb); break;
+        case 3: b = bcast1<3>(nb); break;   case 4: b = bcast1<4>(nb); break;   case 5: b = bcast1<5>(nb); break;
+        case 6: b = bcast1<6>(nb); break;   case 7: b = bcast1<7>(nb); break;   case 8: b = bcast1<8>(nb); break;
+        case 9: b = bcast1<9>(nb); break;   case 10: b = bcast1<10>(nb); break; case 11: b = bcast1<11>(nb); break;
+        case 12: b = bcast1<12>(nb); break; case 13: b = bcast1<13>(nb); break; case 14: b = bcast1<14>(nb); break;
+        default: b = bcast1<15>(nb); break;
+    }
+#pragma unroll
+    for (int c = 0; c < 7; ++c) S[c] = S[c] + b * k[c];
+}
+
 /* S[c] += (nb of lane L of the lane's own row) * k[c] for the seven compartments: v_fmac_f64 with a DPP source is the
  * same fused operation as v_fmac_f64.  The s_nop covers the two wait states a DPP source needs after a VALU
  * write, which the compiler cannot see into the asm to provide.  All 64 lanes are active wherever this is used. */
@@ -306,7 +376,7 @@ __device__ __forceinline__ double wave_div_pop(double x, double pop, double rcpP
  * instruction, tools/ubench/mfma_f64.hip), and the two sequential day chains fill each other's latency gaps.
  * The day loop is straight-line for that reason (its one branch, a capacity correction today, is wave-uniform).
  */
-template <bool FASTDIV>
+template <bool FASTDIV, bool FUSE>
 __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveImage& I, const WaveSlice& W,
                                                   const LaneScalars& lp, unsigned lane, WorkCount& work, PhaseClock& pc,
                                                   double rcpPop, bool& redo) {
@@ -383,8 +453,12 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
             };
             auto run_plain = [&](const LagOps& o) {
                 pc.count(PH_NCHUNK, 1);
-                wave_lags8_lo(Sx, o.t, o.h);
-                wave_lags8_hi(Sx, o.t, o.h + 8);
+                if constexpr (FUSE) {
+                    wave_lags8_lo(Sx, o.t, o.h);
+                    wave_lags8_hi(Sx, o.t, o.h + 8);
+                } else {
+                    strict_lags16(Sx, o.t, o.h);
+                }
             };
             auto run_e = [&](int top, const LagOps& o) {
                 pc.count(PH_NCHUNK_E, 1);
@@ -396,10 +470,14 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
                 const double* ep = hE - top;
 #pragma unroll
                 for (int j = 0; j < MCMC_WV_T; ++j) e[j] = ep[j];
-                wave_lags4_e<0>(Sx, o.t, q, m, o.h, e);
-                wave_lags4_e<4>(Sx, o.t, q, m, o.h + 4, e + 4);
-                wave_lags4_e<8>(Sx, o.t, q, m, o.h + 8, e + 8);
-                wave_lags4_e<12>(Sx, o.t, q, m, o.h + 12, e + 12);
+                if constexpr (FUSE) {
+                    wave_lags4_e<0>(Sx, o.t, q, m, o.h, e);
+                    wave_lags4_e<4>(Sx, o.t, q, m, o.h + 4, e + 4);
+                    wave_lags4_e<8>(Sx, o.t, q, m, o.h + 8, e + 8);
+                    wave_lags4_e<12>(Sx, o.t, q, m, o.h + 12, e + 12);
+                } else {
+                    strict_lags16_e(Sx, o.t, q, m, o.h, e);
+                }
             };
             /* The groups (tops 32 blk + 32, ..., 32, 16) form three runs -- plain, with corrections, plain -- each a
              * tight loop of its own.  A plain run takes two groups per trip, each one's operands requested while the
@@ -481,8 +559,13 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
                 const double* kr = kLane + (MCMC_WV_B - 1 - t) * MCMC_WV_KROW;
                 const LagRow kn = lag_row(min(t + 1, MCMC_WV_B - 1));
                 /* today's new infections into today and the rest of the block (covid.h:403-410) */
-                wave_push7(Sx, (u + MCMC_WV_T - 1) & (MCMC_WV_T - 1), nb, kc.k01[0], kc.k01[1], kc.k23[0], kc.k23[1],
-                           kc.k45[0], kc.k45[1], kc.k6);
+                if constexpr (FUSE) {
+                    wave_push7(Sx, (u + MCMC_WV_T - 1) & (MCMC_WV_T - 1), nb, kc.k01[0], kc.k01[1], kc.k23[0], kc.k23[1],
+                               kc.k45[0], kc.k45[1], kc.k6);
+                } else {
+                    const double k7[7] = {kc.k01[0], kc.k01[1], kc.k23[0], kc.k23[1], kc.k45[0], kc.k45[1], kc.k6};
+                    strict_push7(Sx, (u + MCMC_WV_T - 1) & (MCMC_WV_T - 1), nb, k7);
+                }
                 kc = kn;
                 const double vMI = Sx[0], vHI = Sx[1], vINC = Sx[2], vMILD = Sx[3];
                 double vSER = Sx[4], vREC = Sx[5], vDEAD = Sx[6];
@@ -494,9 +577,9 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
                 eL = extraDeaths > 0 ? extraDeaths : 0.0;
                 const double ne = -eL;
                 vDEAD = vDEAD + eL;                                                 /* today's own sums */
-                vSER = __builtin_fma(ne, ng0S, vSER);
-                vREC = __builtin_fma(ne, ng0R, vREC);
-                vDEAD = __builtin_fma(ne, ng0D, vDEAD);
+                vSER = madd<FUSE>(ne, ng0S, vSER);
+                vREC = madd<FUSE>(ne, ng0R, vREC);
+                vDEAD = madd<FUSE>(ne, ng0D, vDEAD);
                 deadL = vDEAD;
                 /* tomorrow's new infections (covid.h:461-462); asymptomatic == mild buffer */
                 const double nSus = M.pop - vINC - vMILD - vMILD - vSER - vREC - vDEAD;
@@ -517,10 +600,10 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
                     const double e0 = readlane_f64(eL, t), e1 = readlane_f64(eL, 32 + t);
                     const double eb = hiHalf ? e1 : e0, neb = -eb;
                     const double2_t n01 = *(const double2_t*)(kr + 8), n23 = *(const double2_t*)(kr + 10);
-                    Sx[6] = __builtin_fma(eb, n23[1], Sx[6]);                       /* the flat add: 1 within the table's lags */
-                    Sx[4] = __builtin_fma(neb, n01[0], Sx[4]);
-                    Sx[5] = __builtin_fma(neb, n01[1], Sx[5]);
-                    Sx[6] = __builtin_fma(neb, n23[0], Sx[6]);
+                    Sx[6] = madd<FUSE>(eb, n23[1], Sx[6]);                          /* the flat add: 1 within the table's lags */
+                    Sx[4] = madd<FUSE>(neb, n01[0], Sx[4]);
+                    Sx[5] = madd<FUSE>(neb, n01[1], Sx[5]);
+                    Sx[6] = madd<FUSE>(neb, n23[0], Sx[6]);
                 }
                 /* tomorrow's push reads lane u of every row: the second half's lanes get the first half's number (their
                  * own nn is not theirs yet).  v_permlane16_swap exchanges between two registers, hence the second product */
@@ -694,6 +777,7 @@ __device__ inline bool propose_wave(const DevModel& M, Pcg32& rnd, const WaveSli
  * arithmetic and results as mh_step_kernel<T, true, 0, false> (see there for the reference citations).
  * Grid: ceil(nChains / 4) workgroups of 4 waves sharing one LDS image of the tables and the series.
  */
+template <bool FUSE>
 __global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, int n_steps,
                                                       const double* __restrict__ betas,
                                                       const int* __restrict__ flags, int slot0) {
@@ -784,10 +868,10 @@ __global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, 
         {
             const WorkCount work0 = work;
             bool redo = !fastDiv;
-            if (fastDiv) llm = eval_model_wave<true>(M, I, W, lp, lane, work, pc, rcpPop, redo);
+            if (fastDiv) llm = eval_model_wave<true, FUSE>(M, I, W, lp, lane, work, pc, rcpPop, redo);
             if (redo) {
                 work = work0;
-                llm = eval_model_wave<false>(M, I, W, lp, lane, work, pc, rcpPop, redo);
+                llm = eval_model_wave<false, FUSE>(M, I, W, lp, lane, work, pc, rcpPop, redo);
             }
         }
         double llp = 0.0;

@@ -44,9 +44,10 @@ def _oracle_equal(oc, s, c):
     assert oc.rng_state == tuple(int(v) for v in s.rng_state()[c]) and oc.c.n_accept == s.accept_counts()[c]
 
 
-def test_wave_mapping_runs_the_same_chains_as_lane_and_oracle(R11, R10):
-    cfg = make_cfg(40, R11, contract=1, **SMALL)
-    m = O.Model(cfg, R11, contract=1)
+@pytest.mark.parametrize("contract", [1, 0])
+def test_wave_mapping_runs_the_same_chains_as_lane_and_oracle(R11, R10, contract):
+    cfg = make_cfg(40, R11, contract=contract, **SMALL)
+    m = O.Model(cfg, R11, contract=contract)
     xs = perturbed(cfg, 70, 0.05)                      # a ragged ensemble: 70 wavefronts in 18 workgroups
     lane, wave = _pair(cfg, R10, xs, first_chain_id=1)
     sched = (40, 3, 4, 3)
@@ -77,24 +78,25 @@ def test_wave_mapping_runs_the_same_chains_as_lane_and_oracle(R11, R10):
 
 @pytest.mark.parametrize("case", ["overflow", "overflow_fixed_no_prior", "many_breakpoints", "delay_bounds", "plain_target",
                                   "tiny_behaviour"])
-def test_wave_mapping_on_the_models_branches(R11, R10, case):
-    kw, a, steps, target = dict(SMALL), 0.1, 30, ("temp", 1.0)
+@pytest.mark.parametrize("contract", [1, 0])
+def test_wave_mapping_on_the_models_branches(R11, R10, case, contract):
+    kw, a, steps, target = dict(SMALL, contract=contract), 0.1, 30, ("temp", 1.0)
     if case == "overflow":                 # capacity corrections on many days (covid.h:413-429), switching on and off
-        cfg = make_cfg(60, R11, contract=1, cap0=3.0, cap_incr_rate=0.5, initial_beta_mild=1.5, initial_beta_high=4.0, **kw)
+        cfg = make_cfg(60, R11, cap0=3.0, cap_incr_rate=0.5, initial_beta_mild=1.5, initial_beta_high=4.0, **kw)
     elif case == "overflow_fixed_no_prior":
-        cfg = make_cfg(50, R11, contract=1, cap0=3.0, cap_incr_rate=0.5, initial_beta_mild=1.5, initial_beta_high=4.0,
+        cfg = make_cfg(50, R11, cap0=3.0, cap_incr_rate=0.5, initial_beta_mild=1.5, initial_beta_high=4.0,
                        disc_fixed=[0, 1, 0, 1], has_prior=0, **kw)
         a, target = 0.2, ("plain",)
     elif case == "many_breakpoints":
-        cfg = make_cfg(60, R11, contract=1, disc_days=(1, 4, 9, 14, 20, 27, 33, 41), disc_vals=(1, .9, .8, .7, .6, .5, .4, .3),
+        cfg = make_cfg(60, R11, disc_days=(1, 4, 9, 14, 20, 27, 33, 41), disc_vals=(1, .9, .8, .7, .6, .5, .4, .3),
                        disc_fixed=[1, 0, 0, 0, 0, 0, 0, 0], **kw)
         a = 0.02
     elif case == "delay_bounds":
-        cfg = make_cfg(45, R11, contract=1, **kw)
+        cfg = make_cfg(45, R11, **kw)
     elif case == "tiny_behaviour":         # numerators of the day's division down in the denormals: the wave kernel's short
-        cfg = make_cfg(44, R11, contract=1, **kw)          # division hands the evaluation over to the compiler's (wave_div_pop)
+        cfg = make_cfg(44, R11, **kw)          # division hands the evaluation over to the compiler's (wave_div_pop)
     else:
-        cfg = make_cfg(48, R11, contract=1, target_kind="plain", **kw)
+        cfg = make_cfg(48, R11, target_kind="plain", **kw)
         target = ("plain",)
     xs = perturbed(cfg, 66, a)
     if case == "tiny_behaviour":
@@ -111,7 +113,7 @@ def test_wave_mapping_on_the_models_branches(R11, R10, case):
     for s in (lane, wave):
         s.step(steps, 1.0, True)
     _same(lane, wave)
-    m = O.Model(cfg, R11, contract=1)
+    m = O.Model(cfg, R11, contract=contract)
     tgt = O.make_target(*target)
     for c in range(0, 66, 7):
         oc = O.OracleChain(m, c + 1, xs[c])
@@ -190,10 +192,8 @@ def test_wave_mapping_under_a_tempering_ladder(R11, R10):
 
 
 def test_wave_mapping_refuses_what_it_cannot_run(R11, R10):
-    strict = H.CovidSampler(make_cfg(40, R11, contract=0, **SMALL), R10)
-    with pytest.raises(H.McmcHipError, match="contract"):
-        strict.set_mapping("wave")
-    strict.set_chains(perturbed(strict.cfg, 8, 0.05)); assert strict.mapping() == "lane"      # AUTO falls back
+    strict = H.CovidSampler(make_cfg(40, R11, contract=0, **SMALL), R10)      # strict arithmetic runs under both mappings
+    strict.set_chains(perturbed(strict.cfg, 8, 0.05)); assert strict.mapping() == "wave"
     strict.close()
     fast = H.CovidSampler(make_cfg(40, R11, contract=1, **SMALL), R10, precision="f32_model")
     with pytest.raises(H.McmcHipError, match="fast mode"):
