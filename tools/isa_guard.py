@@ -59,6 +59,30 @@ def analyse(workdir):
             out[name] = cur_stats
         if sym.endswith("Li0ELb0EE"):
             m0 = m
+    # the wave mapping (mcmc_wave_kernel.hip.h): its plain lag loop takes two groups of 16 lags x 7 curves per trip
+    for fuse in ("1", "0"):
+        mw = re.search(r"^_Z19mh_step_wave_kernelILb" + fuse + r"EEv[^\n]*:.*?\.end_amdhsa_kernel", asm, re.S | re.M)
+        lines = [t.strip() for t in mw.group(0).split("\n") if t.strip() and not t.strip().startswith((";", "."))]
+        st = {"scratch": sum("scratch_" in t for t in lines), "mfma": sum(t.startswith("v_mfma") for t in lines),
+              "dpp_fmac": sum(t.startswith("v_fmac_f64_dpp") for t in lines),
+              "dpp_mov": sum(t.startswith("v_mov_b64_dpp") for t in lines)}
+        cur, label = None, None
+        for line in mw.group(0).split("\n"):
+            lm = re.match(r"^(\.LBB\d+_\d+):", line)
+            if lm:
+                cur, label = [], lm.group(1)
+                continue
+            t = line.strip()
+            if cur is None or not t or t.startswith((";", ".")):
+                continue
+            cur.append(t)
+            if t.startswith("s_cbranch") and t.split()[-1] == label:          # a single-block loop ends here
+                n = sum(1 for x in cur if x.startswith("v_fmac_f64_dpp"))
+                if fuse == "1" and n == 224:
+                    waits = [int(x) for y in cur for x in re.findall(r"lgkmcnt\((\d+)\)", y)]
+                    st["plain_loop"] = {"instructions": len(cur), "ops": n, "min_lgkmcnt": min(waits) if waits else None}
+                cur = None
+        out["wave_kernel_fused" if fuse == "1" else "wave_kernel_strict"] = st
     m = m0
     vg = re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(0))
     out["vgprs"] = int(vg.group(1)) if vg else None
