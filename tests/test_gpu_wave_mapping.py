@@ -128,6 +128,27 @@ def test_wave_mapping_on_the_models_branches(R11, R10, case, contract):
     lane.close(); wave.close()
 
 
+@pytest.mark.parametrize("n_data", [8, 15, 33, 64, 129])
+def test_wave_mapping_on_odd_series_lengths(R11, R10, n_data):
+    """Series shorter than a block, one day more than a block, exactly two blocks, ...: block and group edges of the
+    wave kernel (32-day blocks, 16-lag groups, 16-term groups of the ordered sums) against the lane kernel and the oracle."""
+    cfg = make_cfg(n_data, R11, contract=1, cap0=40.0, cap_incr_rate=2.0, **SMALL)
+    xs = perturbed(cfg, 5, 0.05)
+    xs[1, -1] = 5.0                        # the latest first day
+    xs[2, -1] = 12.0                       # the earliest
+    lane, wave = _pair(cfg, R10, xs, first_chain_id=1)
+    for s in (lane, wave):
+        s.run(20, 2, 2, 2, record_samples=True, compute_mean=True)
+    _same(lane, wave, FIELDS + ("loglikes", "mean"))
+    m = O.Model(cfg, R11, contract=1)
+    tgt = O.make_target("temp", 1.0)
+    for c in range(5):
+        oc = O.OracleChain(m, c + 1, xs[c])
+        oc.run(tgt, 20, 2, 2, 2)
+        _oracle_equal(oc, wave, c)
+    lane.close(); wave.close()
+
+
 def test_wave_mapping_at_baseline_config_1(R11, R10):
     """BASELINE configs[1]: 1 024 chains x 200 days.  AUTO picks the wave mapping for it; every chain's end state
     after an adjust group and sampling steps equals the lane mapping's, four chains equal the oracle's."""
