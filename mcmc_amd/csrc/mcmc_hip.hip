@@ -335,9 +335,20 @@ void decide_mapping(mcmc_hip_ctx* c) {
 }
 
 int launch_wave_steps(mcmc_hip_ctx* c, int nSteps, const double* dBetas, const int* dFlags, int slot0) {
-    /* as many chains (waves) per workgroup as the LDS holds slices beside the shared image: 4, 2 or 1 */
+    /* As many chains (waves) per workgroup as the LDS holds slices beside the shared image.  Up to one chain per
+     * SIMD of the chip: 4, 2 or 1, every chain a SIMD of its own.  Larger ensembles: 8 or 7 where they fit (two
+     * waves on a SIMD each run at 0.64 of a lone wave's rate: 8 192 chains x 200 days run 24.6 M steps/s with 8 per
+     * workgroup, 20.2 with 7, 19.2 with 4, 17.2 with 6, 15.1 with 5; tools/wpb_sweep.sh; MCMC_WAVE_WPB overrides,
+     * for such measurements). */
     int wpb = MCMC_WAVES_PER_BLOCK;
     while (wpb > 1 && wave_lds_bytes(c->M, c->dim, wpb) > kLdsMax) wpb /= 2;
+    if (c->nChains > (long long)MCMC_WAVES_PER_BLOCK * c->nCU && wpb == MCMC_WAVES_PER_BLOCK)
+        for (int w = MCMC_WV_MAX_WAVES; w >= 7; --w)
+            if (wave_lds_bytes(c->M, c->dim, w) <= kLdsMax) { wpb = w; break; }
+    if (const char* e = getenv("MCMC_WAVE_WPB")) {
+        const int w = atoi(e);
+        if (w >= 1 && w <= MCMC_WV_MAX_WAVES && wave_lds_bytes(c->M, c->dim, w) <= kLdsMax) wpb = w;
+    }
     const unsigned grid = (unsigned)((c->nChains + wpb - 1) / wpb);
     size_t shmem = wave_lds_bytes(c->M, c->dim, wpb);
     if (shmem > kLdsMax) return fail(MCMC_HIP_EINVAL, "the series is too long for a chain's slice of LDS (%zu B > %zu B)", shmem, kLdsMax);

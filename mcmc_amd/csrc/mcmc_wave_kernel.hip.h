@@ -42,6 +42,7 @@
 #define MCMC_WV_B 32          /* days per block: lane l carries day l & 31 of the block for pass l >> 5 */
 #define MCMC_WV_HLO 32        /* zero history entries kept below day 0 (phase A reads down to s - 32) */
 #define MCMC_WV_HHI 32        /* ... and above the simulated horizon (phase A reads up to j0 + 30, as zeros; j0 <= horizon) */
+#define MCMC_WV_MAX_WAVES 8   /* chains (waves) per workgroup at most: two per SIMD */
 #define MCMC_WV_NTAB 10       /* curves of the transposed table: MI HI INC MILD SER REC DEAD, -SFS -RFS -DFS */
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -778,7 +779,7 @@ __device__ inline bool propose_wave(const DevModel& M, Pcg32& rnd, const WaveSli
  * Grid: ceil(nChains / 4) workgroups of 4 waves sharing one LDS image of the tables and the series.
  */
 template <bool FUSE>
-__global__ MCMC_KERNEL_ATTRS void mh_step_wave_kernel(DevModel M, ChainState S, int n_steps,
+__global__ __launch_bounds__(MCMC_WAVE * MCMC_WV_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(1, 2))) void mh_step_wave_kernel(DevModel M, ChainState S, int n_steps,
                                                       const double* __restrict__ betas,
                                                       const int* __restrict__ flags, int slot0) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
