@@ -171,7 +171,8 @@ int mcmc_hip_set_precision(mcmc_hip_ctx* ctx, int32_t mode);
  *         ensembles -- BASELINE.json configs[1]'s 1 024 chains are 16 wavefronts under LANE and 1 024 under
  *         WAVE.  Both arithmetic modes (cfg.contract).  Needs the double-precision mode, the single-region State
  *         and a series that fits a wave's LDS slice (about 1 200 data days); set_mapping(WAVE) fails otherwise.
- *   AUTO  (default) WAVE where possible for ensembles of at most 16 384 chains, else LANE.
+ *   AUTO  (default) WAVE where possible for ensembles of at most 16 384 chains (8 192 / 4 096 where LDS holds only
+ *         two / one chain per workgroup: series beyond about 380 / 710 data days), else LANE.
  * May be called at any time; it takes effect from the next launch.  get_mapping: what the next launch uses. */
 #define MCMC_HIP_MAPPING_AUTO 0
 #define MCMC_HIP_MAPPING_LANE 1

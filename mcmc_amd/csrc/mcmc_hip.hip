@@ -328,10 +328,19 @@ bool wave_mapping_possible(const mcmc_hip_ctx* c, const char** why) {
     if (why) *why = w;
     return w == nullptr;
 }
+/* chains of one workgroup beside the shared image while every chain has a SIMD of its own: 4, 2 or 1 (0: none fits) */
+static int wave_slices_that_fit(const mcmc_hip_ctx* c) {
+    int wpb = MCMC_WAVES_PER_BLOCK;
+    while (wpb > 1 && wave_lds_bytes(c->M, c->dim, wpb) > kLdsMax) wpb /= 2;
+    return wave_lds_bytes(c->M, c->dim, wpb) > kLdsMax ? 0 : wpb;
+}
 void decide_mapping(mcmc_hip_ctx* c) {
     const bool ok = wave_mapping_possible(c, nullptr);
+    /* AUTO: the wave mapping's ceiling is proportional to the chains a CU holds at a time, and so is the ensemble
+     * size at which one chain per lane overtakes it (27 k chains with four per workgroup, tools/mapping_sweep.sh) */
+    const long long autoMax = ok ? (long long)MCMC_WAVE_AUTO_MAX * wave_slices_that_fit(c) / MCMC_WAVES_PER_BLOCK : 0;
     c->useWave = ok && (c->mapping == MCMC_HIP_MAPPING_WAVE ||
-                        (c->mapping == MCMC_HIP_MAPPING_AUTO && c->nChains > 0 && c->nChains <= MCMC_WAVE_AUTO_MAX));
+                        (c->mapping == MCMC_HIP_MAPPING_AUTO && c->nChains > 0 && c->nChains <= autoMax));
 }
 
 int launch_wave_steps(mcmc_hip_ctx* c, int nSteps, const double* dBetas, const int* dFlags, int slot0) {
@@ -340,8 +349,7 @@ int launch_wave_steps(mcmc_hip_ctx* c, int nSteps, const double* dBetas, const i
      * waves on a SIMD each run at 0.64 of a lone wave's rate: 8 192 chains x 200 days run 24.6 M steps/s with 8 per
      * workgroup, 20.2 with 7, 19.2 with 4, 17.2 with 6, 15.1 with 5; tools/wpb_sweep.sh; MCMC_WAVE_WPB overrides,
      * for such measurements). */
-    int wpb = MCMC_WAVES_PER_BLOCK;
-    while (wpb > 1 && wave_lds_bytes(c->M, c->dim, wpb) > kLdsMax) wpb /= 2;
+    int wpb = std::max(wave_slices_that_fit(c), 1);
     if (c->nChains > (long long)MCMC_WAVES_PER_BLOCK * c->nCU && wpb == MCMC_WAVES_PER_BLOCK)
         for (int w = MCMC_WV_MAX_WAVES; w >= 7; --w)
             if (wave_lds_bytes(c->M, c->dim, w) <= kLdsMax) { wpb = w; break; }

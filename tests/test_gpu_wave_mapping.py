@@ -225,6 +225,11 @@ def test_wave_mapping_refuses_what_it_cannot_run(R11, R10):
     with pytest.raises(H.McmcHipError, match="too long"):
         long.set_mapping("wave")
     long.set_chains(H.perturb_ics(CC.initial_params(long.cfg), 8, 0.01)); assert long.mapping() == "lane"
+    mid = H.CovidSampler(make_cfg(500, R11, contract=1), R10)        # two chains per workgroup: AUTO's limit halves
+    x500 = H.perturb_ics(CC.initial_params(mid.cfg), 8193, 0.01)
+    mid.set_chains(x500); assert mid.mapping() == "lane"
+    mid.set_chains(x500[:8192]); assert mid.mapping() == "wave"
+    mid.close()
     with pytest.raises(H.McmcHipError, match="unknown mapping"):
         H._check(H.lib().mcmc_hip_set_mapping(long._h, 9))
     long.close()
