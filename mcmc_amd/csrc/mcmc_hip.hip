@@ -350,12 +350,13 @@ int launch_wave_steps(mcmc_hip_ctx* c, int nSteps, const double* dBetas, const i
      * workgroup, 20.2 with 7, 19.2 with 4, 17.2 with 6, 15.1 with 5; tools/wpb_sweep.sh; MCMC_WAVE_WPB overrides,
      * for such measurements). */
     int wpb = std::max(wave_slices_that_fit(c), 1);
+    const int maxWaves = c->cfg.contract ? MCMC_WV_MAX_WAVES : MCMC_WAVES_PER_BLOCK;      /* the strict kernel's launch bounds */
     if (c->nChains > (long long)MCMC_WAVES_PER_BLOCK * c->nCU && wpb == MCMC_WAVES_PER_BLOCK)
-        for (int w = MCMC_WV_MAX_WAVES; w >= 7; --w)
+        for (int w = maxWaves; w >= 7; --w)
             if (wave_lds_bytes(c->M, c->dim, w) <= kLdsMax) { wpb = w; break; }
     if (const char* e = getenv("MCMC_WAVE_WPB")) {
         const int w = atoi(e);
-        if (w >= 1 && w <= MCMC_WV_MAX_WAVES && wave_lds_bytes(c->M, c->dim, w) <= kLdsMax) wpb = w;
+        if (w >= 1 && w <= maxWaves && wave_lds_bytes(c->M, c->dim, w) <= kLdsMax) wpb = w;
     }
     const unsigned grid = (unsigned)((c->nChains + wpb - 1) / wpb);
     size_t shmem = wave_lds_bytes(c->M, c->dim, wpb);

@@ -778,8 +778,9 @@ __device__ inline bool propose_wave(const DevModel& M, Pcg32& rnd, const WaveSli
  * arithmetic and results as mh_step_kernel<T, true, 0, false> (see there for the reference citations).
  * Grid: ceil(nChains / 4) workgroups of 4 waves sharing one LDS image of the tables and the series.
  */
+/* (the strict form needs more than the 256 registers a second wave per SIMD leaves: four chains per workgroup at most) */
 template <bool FUSE>
-__global__ __launch_bounds__(MCMC_WAVE * MCMC_WV_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(1, 2))) void mh_step_wave_kernel(DevModel M, ChainState S, int n_steps,
+__global__ __launch_bounds__(MCMC_WAVE * (FUSE ? MCMC_WV_MAX_WAVES : MCMC_WAVES_PER_BLOCK)) __attribute__((amdgpu_waves_per_eu(1, 2))) void mh_step_wave_kernel(DevModel M, ChainState S, int n_steps,
                                                       const double* __restrict__ betas,
                                                       const int* __restrict__ flags, int slot0) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
