@@ -175,6 +175,20 @@ def test_wave_mapping_at_baseline_config_1(R11, R10):
     auto.close(); lane.close()
 
 
+def test_wave_mapping_over_a_long_schedule(R11, R10):
+    """300 steps with five adjust groups, burn-in, thinning and the running mean on the 200-day series: every recorded
+    number of 256 chains under the wave mapping equals the lane mapping's (corrections switch on and off along the way)."""
+    cfg = make_cfg(200, R11, contract=1)
+    xs = H.perturb_ics(CC.initial_params(cfg), 256, 0.01)
+    lane, wave = _pair(cfg, R10, xs, first_chain_id=1)
+    for s in (lane, wave):
+        s.run(200, 20, 5, 3, record_samples=True, compute_mean=True)
+    _same(lane, wave, FIELDS + ("loglikes", "mean"))
+    assert np.array_equal(lane.sample_all(0), wave.sample_all(0)) and np.array_equal(lane.sample_all(40), wave.sample_all(40))
+    assert wave.accept_counts().sum() > 0 and np.isfinite(wave.loglike()).all()
+    lane.close(); wave.close()
+
+
 def test_wave_mapping_on_the_365_day_series_and_auto_threshold(R11, R10):
     cfg = make_cfg(365, R11, contract=1)
     xs = H.perturb_ics(CC.initial_params(cfg), 300, 0.01)
