@@ -27,6 +27,10 @@
 #ifndef MCMC_STEPS_PER_LAUNCH
 #define MCMC_STEPS_PER_LAUNCH 16   /* MH steps one mh_step_kernel launch advances every chain by */
 #endif
+#ifndef MCMC_WAVE_STEPS_PER_LAUNCH
+#define MCMC_WAVE_STEPS_PER_LAUNCH 64   /* ... and one mh_step_wave_kernel launch: its launches are short (0.9 ms per 16 steps on BASELINE
+                                           configs[1]), the host's wait for each one and the restaging of its LDS image are 2-3 % of them */
+#endif
 #ifndef MCMC_WAVE_AUTO_MAX
 #define MCMC_WAVE_AUTO_MAX 16384   /* MCMC_HIP_MAPPING_AUTO: ensembles up to this many chains take one chain per wavefront (tools/mapping_sweep.sh) */
 #endif
@@ -885,7 +889,7 @@ int mcmc_hip_step(mcmc_hip_ctx* c, int32_t n_steps, double beta, int32_t random_
     HIP_TRY(hipSetDevice(c->device));
     std::vector<double> betas(n_steps, beta);
     std::vector<int> flags(n_steps, random_subspace ? SF_RANDOM : 0);
-    return run_schedule(c, betas, flags, 0, (size_t)n_steps, MCMC_STEPS_PER_LAUNCH, nullptr);
+    return run_schedule(c, betas, flags, 0, (size_t)n_steps, c->useWave ? MCMC_WAVE_STEPS_PER_LAUNCH : MCMC_STEPS_PER_LAUNCH, nullptr);
 } MCMC_ABI_GUARD
 
 /* ---- tempering ladder (extension) ---- */
@@ -1027,7 +1031,7 @@ int mcmc_hip_run(mcmc_hip_ctx* c, int32_t nSamples, int32_t nBurnin, int32_t nAd
     c->adjustS = c->samplingS = c->kernelS = 0;
     c->kernelLaunches = 0;
     /* launches are cut so that a single kernel stays well below a second */
-    const int perLaunch = MCMC_STEPS_PER_LAUNCH;
+    const int perLaunch = c->useWave ? MCMC_WAVE_STEPS_PER_LAUNCH : MCMC_STEPS_PER_LAUNCH;
     if (int r = run_schedule(c, betas, flags, 0, adjustEnd, perLaunch, &c->adjustS)) return r;
     if (int r = run_schedule(c, betas, flags, adjustEnd, betas.size(), perLaunch, &c->samplingS)) return r;
     if (compute_mean) {                                                /* mcmc.h:1133-1134 (1/0 = inf there too) */

@@ -11,7 +11,7 @@ shutil.copy(os.path.join(src, "bench_stats.json"), os.path.join(dst, f"{tag}_ben
 # the stats pass: bench.py's timed region is its last steps/16 launches of mh_step_kernel (the ones before are
 # the untimed step-size adaptation and warm-up); report their average beside the all-launch average of the stats csv
 bench = json.loads(open(os.path.join(src, "bench_stats.json")).read().strip().splitlines()[-1])
-n_timed = max(1, bench["steps"] // 16)
+n_timed = max(1, int(bench["roofline"].get("launches", bench["steps"] // 16)))
 trace_note = ""
 for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv")):
     rows = [r for r in csv.DictReader(open(f)) if "mh_step" in r["Kernel_Name"]]
