@@ -119,9 +119,11 @@ __device__ __forceinline__ double row_pair_bcast(double v) {
     return EVEN ? a : b;
 }
 
-/* The workgroup's shared image.  (1) The response table CURVE-major, rt[c][lag]: phase A gives lane n of every row
- * the 16 lags of a group (one conflict-free read per curve) and broadcasts them with DPP.  The three FromSerious
- * curves are stored negated: fma(e, -g, s) is fma(-e, g, s), bit for bit.  (2) The per-day constants and the
+/* The workgroup's shared image.  (1) The response table: phase A gives lane n of every 16-lane row the table at lag
+ * (top - n) and broadcasts it with DPP.  The seven curves of a lag are one row of SEVEN doubles, rt[lag][7] -- one
+ * address per group, the curves at constant offsets; rows 56 bytes apart put the 16 lanes of a row on 16 different
+ * bank pairs (14 n mod 64 is distinct for n = 0..15).  The three FromSerious curves, used only by the groups with
+ * corrections, follow curve-major, rn[c][lag], and negated: fma(e, -g, s) is fma(-e, g, s), bit for bit.  (2) The per-day constants and the
  * observed series, as stage_lds.  (3) The phase-B lag table: row (lag + B - 1) holds, for the lags -(B-1) .. B-1
  * between a destination day of a block and the block's current day, what a destination multiplies today's numbers
  * with -- [0..7] the row of Rpos (today's new infections; zeros for lag < 0: the destination's day is over) and
@@ -129,7 +131,8 @@ __device__ __forceinline__ double row_pair_bcast(double v) {
  * registers, covid.h:413-429).  Zeros make the multiply-add leave a finished sum as it is, which phase B relies on. */
 struct WaveImage {
     LdsView lds;              /* capacity, deaths, sigma2, seg (no row-major tables) */
-    const double* rt;         /* [MCMC_WV_NTAB][rows] */
+    const double* rt;         /* [rows][7]: MI HI INC MILD SER REC DEAD */
+    const double* rn;         /* [3][rows]: -SFS -RFS -DFS */
     const double* lagTab;     /* [MCMC_WV_KROWS][MCMC_WV_KROW] */
     int rows;
 };
@@ -141,11 +144,14 @@ __device__ inline WaveImage stage_wave_image(const DevModel& M, double* lds_raw)
     double* sg2 = dea + M.nData;
     int* seg = (int*)(sg2 + M.nData);
     double* kt = lds_raw + wave_image_doubles(M);
-    for (int i = threadIdx.x; i < MCMC_WV_NTAB * rows; i += blockDim.x) {
+    double* rn = rt + (size_t)7 * rows;
+    for (int i = threadIdx.x; i < 7 * rows; i += blockDim.x) {
+        const int L = i / 7, c = i % 7;
+        rt[i] = L < M.nLagRows ? M.Rpos[(size_t)L * 8 + c] : 0.0;
+    }
+    for (int i = threadIdx.x; i < 3 * rows; i += blockDim.x) {
         const int c = i / rows, L = i % rows;
-        double v = 0.0;
-        if (L < M.nLagRows) v = c < 7 ? M.Rpos[(size_t)L * 8 + c] : -M.Rneg[(size_t)L * 4 + (c - 7)];
-        rt[i] = v;
+        rn[i] = L < M.nLagRows ? -M.Rneg[(size_t)L * 4 + c] : 0.0;
     }
     for (int i = threadIdx.x; i < M.simPad; i += blockDim.x) {
         cap[i] = M.capacity[i];
@@ -168,7 +174,7 @@ __device__ inline WaveImage stage_wave_image(const DevModel& M, double* lds_raw)
     WaveImage I;
     I.lds.Rpos = nullptr; I.lds.Rneg = nullptr; I.lds.capacity = cap; I.lds.deaths = dea; I.lds.sigma2 = sg2; I.lds.seg = seg;
     I.lds.tabF = nullptr; I.lds.tabN = nullptr; I.lds.rowsB = nullptr; I.lds.rowsNB = nullptr; I.lds.tr = nullptr;
-    I.rt = rt; I.lagTab = kt; I.rows = rows;
+    I.rt = rt; I.rn = rn; I.lagTab = kt; I.rows = rows;
     return I;
 }
 
@@ -445,9 +451,9 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
             const double* const hE = heDst + iB;
             struct LagOps { double t[7]; double h[MCMC_WV_T]; };
             auto load_ops = [&](int top, LagOps& o) {
-                const double* tp = I.rt + min(top - n16, rowsM1);
+                const double* tp = I.rt + min(top - n16, rowsM1) * 7;
 #pragma unroll
-                for (int c = 0; c < 7; ++c) o.t[c] = tp[c * I.rows];
+                for (int c = 0; c < 7; ++c) o.t[c] = tp[c];
                 const double* hp = hN - top;
 #pragma unroll
                 for (int j = 0; j < MCMC_WV_T; ++j) o.h[j] = hp[j];
@@ -464,7 +470,7 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
             auto run_e = [&](int top, const LagOps& o) {
                 pc.count(PH_NCHUNK_E, 1);
                 const int lagN = top - n16;
-                const double* tp = I.rt + min(lagN, rowsM1) + 7 * I.rows;
+                const double* tp = I.rn + min(lagN, rowsM1);
                 const double q[3] = {tp[0], tp[I.rows], tp[2 * I.rows]};
                 const double m = lagN < M.nLagRows ? 1.0 : 0.0;
                 double e[MCMC_WV_T];

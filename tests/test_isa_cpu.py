@@ -33,10 +33,10 @@ def test_lag_loops_keep_their_prefetch_in_flight(tmp_path):
     assert fplain["sgpr_spill_moves"] == 0 and feterm["sgpr_spill_moves"] == 0
     assert fplain["min_vmcnt"] >= 8 and feterm["min_vmcnt"] >= 16
     # the wave mapping (mcmc_wave_kernel.hip.h): no scratch, no matrix instruction; its plain lag loop takes two groups of
-    # 16 lags x 7 curves per trip (224 DPP multiply-adds + 30 LDS reads and their addresses) and waits only for the group
-    # it is about to use (lgkmcnt(14): the other group's 15 reads stay in flight)
+    # 16 lags x 7 curves per trip (224 DPP multiply-adds + 24 LDS reads and their addresses) and waits only for the group
+    # it is about to use (lgkmcnt(12): the other group's 12 reads stay in flight)
     wf, ws = r["wave_kernel_fused"], r["wave_kernel_strict"]
     assert wf["scratch"] == 0 and ws["scratch"] == 0 and wf["mfma"] == 0 and ws["mfma"] == 0
     assert wf["dpp_mov"] == 0 and ws["dpp_mov"] > 1000            # the strict form broadcasts with a move of its own
-    assert wf["plain_loop"]["ops"] == 224 and wf["plain_loop"]["instructions"] <= 300
+    assert wf["plain_loop"]["ops"] == 224 and wf["plain_loop"]["instructions"] <= 280
     assert wf["plain_loop"]["min_lgkmcnt"] >= 12
