@@ -188,19 +188,15 @@ __device__ inline WaveImage stage_wave_image(const DevModel& M, double* lds_raw)
     MCMC_WV_F("%6", "%[t6]", H, L)
 #define MCMC_WV_S7 "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(S[4]), "+v"(S[5]), "+v"(S[6])
 #define MCMC_WV_T7 [t0] "v"(t[0]), [t1] "v"(t[1]), [t2] "v"(t[2]), [t3] "v"(t[3]), [t4] "v"(t[4]), [t5] "v"(t[5]), [t6] "v"(t[6])
-__device__ __forceinline__ void wave_lags8_lo(double (&S)[7], const double (&t)[7], const double* h) {
+__device__ __forceinline__ void wave_lags16(double (&S)[7], const double (&t)[7], const double* h) {
     asm("s_nop 1\n\t" MCMC_WV_LAG7("%[h0]", 0) MCMC_WV_LAG7("%[h1]", 1) MCMC_WV_LAG7("%[h2]", 2) MCMC_WV_LAG7("%[h3]", 3)
         MCMC_WV_LAG7("%[h4]", 4) MCMC_WV_LAG7("%[h5]", 5) MCMC_WV_LAG7("%[h6]", 6) MCMC_WV_LAG7("%[h7]", 7)
+        MCMC_WV_LAG7("%[h8]", 8) MCMC_WV_LAG7("%[h9]", 9) MCMC_WV_LAG7("%[h10]", 10) MCMC_WV_LAG7("%[h11]", 11)
+        MCMC_WV_LAG7("%[h12]", 12) MCMC_WV_LAG7("%[h13]", 13) MCMC_WV_LAG7("%[h14]", 14) MCMC_WV_LAG7("%[h15]", 15)
         : MCMC_WV_S7
         : MCMC_WV_T7, [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [h3] "v"(h[3]), [h4] "v"(h[4]), [h5] "v"(h[5]),
-          [h6] "v"(h[6]), [h7] "v"(h[7]));
-}
-__device__ __forceinline__ void wave_lags8_hi(double (&S)[7], const double (&t)[7], const double* h) {
-    asm("s_nop 1\n\t" MCMC_WV_LAG7("%[h0]", 8) MCMC_WV_LAG7("%[h1]", 9) MCMC_WV_LAG7("%[h2]", 10) MCMC_WV_LAG7("%[h3]", 11)
-        MCMC_WV_LAG7("%[h4]", 12) MCMC_WV_LAG7("%[h5]", 13) MCMC_WV_LAG7("%[h6]", 14) MCMC_WV_LAG7("%[h7]", 15)
-        : MCMC_WV_S7
-        : MCMC_WV_T7, [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [h3] "v"(h[3]), [h4] "v"(h[4]), [h5] "v"(h[5]),
-          [h6] "v"(h[6]), [h7] "v"(h[7]));
+          [h6] "v"(h[6]), [h7] "v"(h[7]), [h8] "v"(h[8]), [h9] "v"(h[9]), [h10] "v"(h[10]), [h11] "v"(h[11]),
+          [h12] "v"(h[12]), [h13] "v"(h[13]), [h14] "v"(h[14]), [h15] "v"(h[15]));
 }
 /* the same for four lags whose source days may carry capacity corrections: after the seven projections of a source
  * day come + e (deaths; m = 1 within the table's lags, the flat add() of covid.h:387-391) and the three negative
@@ -461,8 +457,7 @@ __device__ __forceinline__ double eval_model_wave(const DevModel& M, const WaveI
             auto run_plain = [&](const LagOps& o) {
                 pc.count(PH_NCHUNK, 1);
                 if constexpr (FUSE) {
-                    wave_lags8_lo(Sx, o.t, o.h);
-                    wave_lags8_hi(Sx, o.t, o.h + 8);
+                    wave_lags16(Sx, o.t, o.h);
                 } else {
                     strict_lags16(Sx, o.t, o.h);
                 }
