@@ -43,7 +43,7 @@
 #define MCMC_WV_HLO 32        /* zero history entries kept below day 0 (phase A reads down to s - 32) */
 #define MCMC_WV_HHI 32        /* ... and above the simulated horizon (phase A reads up to j0 + 30, as zeros; j0 <= horizon) */
 #define MCMC_WV_MAX_WAVES 8   /* chains (waves) per workgroup at most: two per SIMD */
-#define MCMC_WV_NTAB 10       /* curves of the transposed table: MI HI INC MILD SER REC DEAD, -SFS -RFS -DFS */
+#define MCMC_WV_NTAB 10       /* doubles per lag of the table in LDS: MI HI INC MILD SER REC DEAD (one row), -SFS -RFS -DFS (curve-major) */
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 #define MCMC_WV_KROW 12       /* doubles per row of the phase-B lag table: the 8 of Rpos, the 4 of Rneg */
@@ -53,13 +53,13 @@ __host__ __device__ inline size_t wave_slice_doubles(const DevModel& M, int dim)
     const size_t histLen = (size_t)M.simDays + MCMC_WV_HLO + MCMC_WV_HHI;
     return 4 * histLen + 2 * (size_t)M.nData + 2 * (size_t)dim;
 }
-/* rows (lags) of the transposed table in LDS: phase A reads lags up to (days simulated so far) + 32; every lag from
+/* rows (lags) of the table in LDS: phase A reads lags up to (days simulated so far) + 32; every lag from
  * nLagRows on is a zero (the d < nDays cut-off of project(), covid.h:378) and reads the one zero row kept for them */
 __host__ __device__ inline int wave_tab_rows(const DevModel& M) {
     const int a = M.simDays + MCMC_WV_B + 1, b = M.nLagRows + 1;
     return a < b ? a : b;
 }
-/* doubles of the part of LDS the waves of a workgroup share (stage_wave_image): the table, curve-major; capacity,
+/* doubles of the part of LDS the waves of a workgroup share (stage_wave_image): the table; capacity,
  * deaths, sigma^2; the segment index (ints); then, 16-byte aligned, the phase-B lag table */
 __host__ __device__ inline size_t wave_image_doubles(const DevModel& M) {
     const size_t d = (size_t)MCMC_WV_NTAB * wave_tab_rows(M) + (size_t)M.simPad + 2 * (size_t)M.nData + ((size_t)M.simPad + 1) / 2;
@@ -139,7 +139,7 @@ struct WaveImage {
 __device__ inline WaveImage stage_wave_image(const DevModel& M, double* lds_raw) {
     const int rows = wave_tab_rows(M);
     double* rt = lds_raw;
-    double* cap = rt + (size_t)MCMC_WV_NTAB * rows;
+    double* cap = rt + (size_t)MCMC_WV_NTAB * rows;             /* behind rt[rows][7] and rn[3][rows] */
     double* dea = cap + M.simPad;
     double* sg2 = dea + M.nData;
     int* seg = (int*)(sg2 + M.nData);
